@@ -1,0 +1,267 @@
+/*
+ * ptc.h -- C ABI of libptcore, the MI355X (gfx950) path-tracing core.
+ *
+ * The library replaces one hot path of mschertenleib/path_tracer: the Vulkan
+ * KHR ray-tracing pipeline behind the renderer interface of
+ * src/renderer.hpp:256-278 (create_render_resources / draw_frame /
+ * reset_render / write_to_png) together with the device programs in
+ * src/shaders. Each entry point below names the reference interface it stands
+ * in for. Plain pointers and sizes only; no C++ or framework types cross this
+ * boundary. All functions return PTC_OK (0) or a negative PTC_E_* code; the
+ * message for the calling thread's last failure is ptc_last_error().
+ *
+ * Threading: a context owns one HIP device and one stream. Calls on one
+ * context are ordered on that stream and must not be issued concurrently
+ * from several host threads. The read-back calls synchronise the stream.
+ */
+#ifndef PTC_H
+#define PTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTC_OK 0
+#define PTC_E_INVALID (-1)   /* bad argument */
+#define PTC_E_DEVICE (-2)    /* HIP runtime failure */
+#define PTC_E_NOMEM (-3)
+#define PTC_E_IO (-4)
+#define PTC_E_LIMIT (-5)     /* size beyond a documented maximum */
+
+/* Material kinds: the reference's shader-binding-table record offset
+ * (src/renderer.cpp:1170, hit groups in the order of :1548-1567). */
+#define PTC_KIND_DIFFUSE 0u    /* src/shaders/diffuse.rchit */
+#define PTC_KIND_SPECULAR 1u   /* src/shaders/specular.rchit */
+#define PTC_KIND_EMISSIVE 2u   /* src/shaders/emissive.rchit */
+#define PTC_KIND_DIELECTRIC 3u /* src/shaders/dielectric.rchit */
+
+#define PTC_NO_HIT 0xffffffffu
+
+typedef struct ptc_context ptc_context;
+typedef struct ptc_scene ptc_scene;
+typedef struct ptc_film ptc_film;
+
+typedef struct ptc_vec3
+{
+    float x, y, z;
+} ptc_vec3; /* src/vec3.hpp:6-16 */
+
+/* Byte-identical to the reference's Camera (src/camera.hpp:6-19), so the
+ * output of its create_camera() can be passed straight through. */
+typedef struct ptc_camera
+{
+    float distance;
+    ptc_vec3 position;
+    ptc_vec3 target;
+    ptc_vec3 direction_x; /* right */
+    ptc_vec3 direction_y; /* down */
+    ptc_vec3 direction_z; /* forward */
+    float sensor_distance;
+    float sensor_half_width;
+    float sensor_half_height;
+    float focus_distance;
+    float aperture_radius;
+} ptc_camera;
+
+/* One triangle mesh: the three arrays create_render_resources() uploads from
+ * aiScene::mMeshes[i] (src/renderer.cpp:1818-1838). Host pointers; copied. */
+typedef struct ptc_mesh_desc
+{
+    const float *positions;  /* 3 * n_vertices  (aiMesh::mVertices) */
+    const float *normals;    /* 3 * n_vertices  (aiMesh::mNormals) */
+    const uint32_t *indices; /* 3 * n_triangles (flattened aiMesh::mFaces) */
+    uint32_t n_vertices;
+    uint32_t n_triangles;
+} ptc_mesh_desc;
+
+/* One TLAS instance (src/renderer.cpp:1147-1174): 3x4 row-major
+ * object-to-world transform (VkTransformMatrixKHR layout), the mesh it
+ * instantiates and its material kind. */
+typedef struct ptc_instance_desc
+{
+    float transform[12];
+    uint32_t mesh;
+    uint32_t kind;
+} ptc_instance_desc;
+
+/* Equirectangular RGBA32F environment map (src/renderer.cpp:1840-1938,
+ * sampled by src/shaders/shader.rmiss:20-24). rgba == NULL selects the
+ * two-tone sky of shader.rmiss:13-18. */
+typedef struct ptc_envmap_desc
+{
+    const float *rgba; /* 4 * width * height, row-major, row 0 = v 0 */
+    uint32_t width;
+    uint32_t height;
+} ptc_envmap_desc;
+
+typedef struct ptc_build_options
+{
+    /* Neighbourhood (in Morton order) each cluster searches for its merge
+     * partner during the bottom-up build; 0 selects the default of 16,
+     * values above 32 are clamped. Larger = better tree, slower build. */
+    uint32_t search_radius;
+    uint32_t reserved[7];
+} ptc_build_options;
+
+typedef struct ptc_scene_info
+{
+    uint32_t n_triangles;  /* flattened over instances */
+    uint32_t n_nodes;      /* 80-byte wide nodes */
+    uint32_t n_instances;
+    uint32_t bvh_depth;    /* levels of the wide tree */
+    float build_ms;        /* device time of the BVH build */
+    float sah_cost;        /* SAH cost of the wide tree (Ct = Cn = 1) */
+    uint64_t device_bytes; /* HBM held by the scene */
+} ptc_scene_info;
+
+/* 80-byte wide-BVH node and 48-byte triangle as they lie in HBM; returned by
+ * ptc_scene_read_bvh() so a checker can validate and traverse the tree. */
+typedef struct ptc_bvh8_node
+{
+    float origin[3];      /* lower corner of the node's quantisation grid */
+    uint8_t exp[3];       /* per-axis grid step 2^(exp-127), as exponent bits */
+    uint8_t imask;        /* bit s: slot s holds an internal node */
+    uint32_t child_base;  /* first internal child; the rest follow in slot order */
+    uint32_t tri_base;    /* first triangle of this node's leaf slots */
+    uint8_t meta[8];      /* 0 empty; internal 0x20|(24+s); leaf (unary n<<5)|offset */
+    uint8_t qlo[3][8];    /* qlo[axis][slot] */
+    uint8_t qhi[3][8];
+} ptc_bvh8_node;
+
+typedef struct ptc_bvh_triangle
+{
+    float v0[3];
+    uint32_t instance;
+    float e1[3];
+    uint32_t primitive;
+    float e2[3];
+    uint32_t flat; /* index in instance-major order; the tie-break key */
+} ptc_bvh_triangle;
+
+typedef struct ptc_hit
+{
+    float t, u, v;
+    uint32_t flat; /* PTC_NO_HIT on a miss */
+} ptc_hit;
+
+#define PTC_INTEGRATOR_MEGAKERNEL 0u /* one lane walks one pixel's paths */
+#define PTC_INTEGRATOR_WAVEFRONT 1u  /* ray queues, compaction between bounces */
+
+#define PTC_ACCUM_RUNNING_MEAN 0u /* reference semantics (shader.rgen:202-216) */
+#define PTC_ACCUM_SUM 1u          /* un-normalised sum, for sharding samples */
+
+/* One or more dispatches of the ray-generation program. Dispatch k of
+ * n_frames uses global_frame_count + k and continues the film's sample
+ * count, exactly as n_frames consecutive draw_frame() calls would
+ * (src/renderer.cpp:2064-2110, :2224). */
+typedef struct ptc_render_params
+{
+    uint32_t global_frame_count; /* Push_constants::global_frame_count */
+    uint32_t samples_per_frame;  /* Push_constants::samples_per_frame */
+    uint32_t n_frames;           /* consecutive dispatches in this call (>= 1) */
+    uint32_t frame_stride;       /* frame count step between dispatches (0 -> 1) */
+    uint32_t max_depth;          /* the literal 32 of shader.rgen:65 (0 -> 32) */
+    float tmax;                  /* the literal 10000.0 of shader.rgen:77 (0 -> 10000) */
+    uint32_t integrator;         /* PTC_INTEGRATOR_* */
+    uint32_t accumulate;         /* PTC_ACCUM_* */
+    uint32_t reserved[4];
+} ptc_render_params;
+
+typedef struct ptc_stats
+{
+    uint64_t rays;   /* closest-hit queries since the last reset */
+    uint64_t paths;  /* camera samples */
+    uint64_t nodes_visited; /* counted only by instrumented calls */
+    uint64_t tris_tested;
+    double render_ms; /* device time of the last ptc_render */
+} ptc_stats;
+
+/* ---- context: stands in for create_context() (src/renderer.hpp:256) ------ */
+int ptc_context_create(int device_ordinal, ptc_context **out);
+void ptc_context_destroy(ptc_context *ctx);
+/* Use an existing HIP stream (hipStream_t) for all work of this context. */
+int ptc_context_set_stream(ptc_context *ctx, void *hip_stream);
+const char *ptc_last_error(void);
+
+/* ---- scene: the geometry upload + BLAS/TLAS build + environment-map upload
+ * of create_render_resources() (src/renderer.cpp:1818-1941). Builds the wide
+ * BVH on the device. opts may be NULL. */
+int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes,
+                     uint32_t n_meshes, const ptc_instance_desc *instances,
+                     uint32_t n_instances, const ptc_envmap_desc *envmap,
+                     const ptc_build_options *opts, ptc_scene **out);
+void ptc_scene_destroy(ptc_scene *scene);
+int ptc_scene_get_info(const ptc_scene *scene, ptc_scene_info *out);
+/* Copy the device BVH to host buffers (sizes from ptc_scene_get_info). */
+int ptc_scene_read_bvh(const ptc_scene *scene, ptc_bvh8_node *nodes,
+                       size_t n_nodes, ptc_bvh_triangle *triangles,
+                       size_t n_triangles);
+
+/* ---- film: the RGBA32F storage image + RGBA8 render target + sample
+ * counters of Vulkan_render_resources (src/renderer.hpp:225-228, :251-253).
+ * accum_dev / rgba8_dev may point at caller-owned device memory
+ * (16 * w * h and 4 * w * h bytes) or be NULL to let the library allocate. */
+int ptc_film_create(ptc_context *ctx, uint32_t width, uint32_t height,
+                    void *accum_dev, void *rgba8_dev, ptc_film **out);
+void ptc_film_destroy(ptc_film *film);
+/* reset_render() (src/renderer.cpp:2236-2239): sample_count = 0. */
+int ptc_film_reset(ptc_film *film);
+uint32_t ptc_film_sample_count(const ptc_film *film);
+/* Continue from an externally supplied sample count (sharded rendering). */
+int ptc_film_set_sample_count(ptc_film *film, uint32_t sample_count);
+int ptc_film_read_accum(ptc_film *film, float *rgba_out);    /* 4*w*h floats */
+int ptc_film_read_rgba8(ptc_film *film, uint8_t *rgba_out);  /* 4*w*h bytes */
+void *ptc_film_accum_device_ptr(ptc_film *film);
+/* Tone-map the accumulator into the RGBA8 target again (after an external
+ * reduction wrote the accumulator). sum_mode: divide rgb by alpha first. */
+int ptc_film_resolve(ptc_film *film, int sum_mode);
+
+/* ---- render: the traced part of draw_frame() (src/renderer.cpp:2064-2110),
+ * i.e. vkCmdTraceRaysKHR(W, H, 1) with the push constants built from camera. */
+int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
+               const ptc_camera *camera, const ptc_render_params *params);
+
+/* Flattened triangle index hit by the first sample's camera ray of every
+ * pixel for one dispatch (the hit the reference would report through
+ * gl_InstanceID / gl_PrimitiveID at bounce 0). ids_out: w*h host uint32. */
+int ptc_primary_hits(ptc_context *ctx, const ptc_scene *scene,
+                     const ptc_camera *camera, uint32_t width, uint32_t height,
+                     uint32_t global_frame_count, float tmax,
+                     uint32_t *ids_out);
+
+/* Closest-hit queries for caller-supplied rays: one traceRayEXT each
+ * (shader.rgen:68-78: opaque, no culling, tmin 0). rays = 6 floats per ray
+ * (origin, direction). Host pointers. counters may be NULL; when given the
+ * call runs the instrumented kernel and adds nodes/triangles visited. */
+int ptc_trace_rays(ptc_context *ctx, const ptc_scene *scene, const float *rays,
+                   size_t n_rays, float tmax, ptc_hit *hits_out,
+                   ptc_stats *counters);
+/* Same with device pointers; nothing is copied or synchronised. */
+int ptc_trace_rays_device(ptc_context *ctx, const ptc_scene *scene,
+                          const void *rays_dev, size_t n_rays, float tmax,
+                          void *hits_dev);
+
+int ptc_get_stats(ptc_context *ctx, ptc_stats *out);
+int ptc_reset_stats(ptc_context *ctx);
+int ptc_synchronize(ptc_context *ctx);
+
+/* write_to_png() (src/renderer.cpp:2241-2327, src/utility.cpp:94-111):
+ * read the RGBA8 target back and write a 4-channel PNG with stride 4*w.
+ * Returns PTC_OK, or PTC_E_IO with the reference's message text in
+ * ptc_last_error(). */
+int ptc_write_png(ptc_film *film, const char *file_name);
+
+/* Element-wise evaluation of the device math primitives the kernels use, so
+ * a checker can compare them with its own: fn 0 sincos(a) -> out, out2;
+ * 1 log(a); 2 acos(a); 3 atan2(a, b); 4 a / b; 5 sqrt(a);
+ * 6 (float)(uint32 bits of a) * 2^-32. Host pointers, n floats each. */
+int ptc_math_eval(ptc_context *ctx, int fn, const float *a, const float *b,
+                  float *out, float *out2, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTC_H */

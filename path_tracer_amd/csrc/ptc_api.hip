@@ -1,0 +1,956 @@
+// C ABI of libptcore (include/ptc.h): contexts, scene upload, films, render
+// dispatch bookkeeping, read-back and PNG output.
+#include "ptc_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace ptc
+{
+
+static thread_local std::string g_error;
+
+void set_error(const std::string &msg)
+{
+    g_error = msg;
+}
+
+namespace
+{
+
+// Inverse of a 3x4 affine matrix: cofactor formula in double, rounded once to
+// float. Stands in for the driver's gl_WorldToObjectEXT.
+void inverse_affine(const float m[12], float out[12])
+{
+    const double a = m[0], b = m[1], c = m[2], tx = m[3];
+    const double d = m[4], e = m[5], f = m[6], ty = m[7];
+    const double g = m[8], h = m[9], i = m[10], tz = m[11];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    const double r = 1.0 / det;
+    const double i00 = (e * i - f * h) * r, i01 = (c * h - b * i) * r, i02 = (b * f - c * e) * r;
+    const double i10 = (f * g - d * i) * r, i11 = (a * i - c * g) * r, i12 = (c * d - a * f) * r;
+    const double i20 = (d * h - e * g) * r, i21 = (b * g - a * h) * r, i22 = (a * e - b * d) * r;
+    out[0] = (float)i00;
+    out[1] = (float)i01;
+    out[2] = (float)i02;
+    out[3] = (float)(-(i00 * tx + i01 * ty + i02 * tz));
+    out[4] = (float)i10;
+    out[5] = (float)i11;
+    out[6] = (float)i12;
+    out[7] = (float)(-(i10 * tx + i11 * ty + i12 * tz));
+    out[8] = (float)i20;
+    out[9] = (float)i21;
+    out[10] = (float)i22;
+    out[11] = (float)(-(i20 * tx + i21 * ty + i22 * tz));
+}
+
+vec3 to_v3(const ptc_vec3 &v)
+{
+    vec3 r;
+    r.x = v.x;
+    r.y = v.y;
+    r.z = v.z;
+    return r;
+}
+
+// Push_constants as draw_frame() fills them (src/renderer.cpp:2082-2094).
+DFrame make_frame(const ptc_camera &cam, uint32_t width, uint32_t height)
+{
+    DFrame F{};
+    F.camera_position = to_v3(cam.position);
+    F.camera_dir_x = to_v3(cam.direction_x);
+    F.camera_dir_y = to_v3(cam.direction_y);
+    F.camera_dir_z = to_v3(cam.direction_z);
+    F.sensor_distance = cam.sensor_distance;
+    F.sensor_half_width = cam.sensor_half_width;
+    F.sensor_half_height = cam.sensor_half_height;
+    F.focus_distance = cam.focus_distance;
+    F.aperture_radius = cam.aperture_radius;
+    F.width = width;
+    F.height = height;
+    F.max_depth = 32;
+    F.tmax = 10000.0f;
+    F.n_frames = 1;
+    F.frame_stride = 1;
+    F.samples_per_frame = 1;
+    return F;
+}
+
+int use_device(const ptc_context *ctx)
+{
+    PTC_HIP_CHECK(hipSetDevice(ctx->device));
+    return PTC_OK;
+}
+
+// ---- minimal PNG writer (8-bit RGBA, stored deflate blocks) -------------------
+
+uint32_t crc_table[256];
+bool crc_ready = false;
+
+uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n)
+{
+    if (!crc_ready)
+    {
+        for (uint32_t i = 0; i < 256; ++i)
+        {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k)
+            {
+                c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            }
+            crc_table[i] = c;
+        }
+        crc_ready = true;
+    }
+    for (size_t i = 0; i < n; ++i)
+    {
+        crc = crc_table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    }
+    return crc;
+}
+
+void put_be32(std::vector<uint8_t> &v, uint32_t x)
+{
+    v.push_back((uint8_t)(x >> 24));
+    v.push_back((uint8_t)(x >> 16));
+    v.push_back((uint8_t)(x >> 8));
+    v.push_back((uint8_t)x);
+}
+
+void put_chunk(std::vector<uint8_t> &png, const char type[4], const std::vector<uint8_t> &data)
+{
+    put_be32(png, (uint32_t)data.size());
+    const size_t start = png.size();
+    png.insert(png.end(), type, type + 4);
+    png.insert(png.end(), data.begin(), data.end());
+    const uint32_t crc = crc32_update(0xffffffffu, png.data() + start, png.size() - start) ^ 0xffffffffu;
+    put_be32(png, crc);
+}
+
+bool write_png_rgba8(const char *file_name, const uint8_t *rgba, uint32_t w, uint32_t h)
+{
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * (4 * (size_t)w + 1));
+    for (uint32_t y = 0; y < h; ++y)
+    {
+        raw.push_back(0); // filter: none
+        raw.insert(raw.end(), rgba + (size_t)y * w * 4, rgba + (size_t)(y + 1) * w * 4);
+    }
+    std::vector<uint8_t> z;
+    z.push_back(0x78);
+    z.push_back(0x01);
+    uint32_t s1 = 1, s2 = 0;
+    size_t pos = 0;
+    do
+    {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xff));
+        z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xff));
+        z.push_back((uint8_t)((~n >> 8) & 0xff));
+        for (size_t i = 0; i < n; ++i)
+        {
+            const uint8_t b = raw[pos + i];
+            z.push_back(b);
+            s1 = (s1 + b) % 65521u;
+            s2 = (s2 + s1) % 65521u;
+        }
+        pos += n;
+    } while (pos < raw.size());
+    put_be32(z, (s2 << 16) | s1);
+
+    std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, w);
+    put_be32(ihdr, h);
+    ihdr.push_back(8); // bit depth
+    ihdr.push_back(6); // RGBA
+    ihdr.push_back(0);
+    ihdr.push_back(0);
+    ihdr.push_back(0);
+    put_chunk(png, "IHDR", ihdr);
+    put_chunk(png, "IDAT", z);
+    put_chunk(png, "IEND", {});
+    FILE *f = std::fopen(file_name, "wb");
+    if (!f)
+    {
+        return false;
+    }
+    const bool ok = std::fwrite(png.data(), 1, png.size(), f) == png.size();
+    return std::fclose(f) == 0 && ok;
+}
+
+} // namespace
+} // namespace ptc
+
+using namespace ptc;
+
+extern "C" {
+
+const char *ptc_last_error(void)
+{
+    return g_error.c_str();
+}
+
+int ptc_context_create(int device_ordinal, ptc_context **out)
+{
+    if (!out)
+    {
+        set_error("ptc_context_create: out is NULL");
+        return PTC_E_INVALID;
+    }
+    *out = nullptr;
+    int n_dev = 0;
+    PTC_HIP_CHECK(hipGetDeviceCount(&n_dev));
+    if (device_ordinal < 0 || device_ordinal >= n_dev)
+    {
+        set_error("ptc_context_create: no such device");
+        return PTC_E_INVALID;
+    }
+    PTC_HIP_CHECK(hipSetDevice(device_ordinal));
+    ptc_context *ctx = new (std::nothrow) ptc_context();
+    if (!ctx)
+    {
+        set_error("out of host memory");
+        return PTC_E_NOMEM;
+    }
+    ctx->device = device_ordinal;
+    hipDeviceProp_t prop;
+    PTC_HIP_CHECK(hipGetDeviceProperties(&prop, device_ordinal));
+    ctx->n_cus = prop.multiProcessorCount;
+    PTC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+    PTC_HIP_CHECK(hipMalloc(&ctx->d_stats, sizeof(DeviceStats)));
+    PTC_HIP_CHECK(hipMemsetAsync(ctx->d_stats, 0, sizeof(DeviceStats), ctx->stream));
+    PTC_HIP_CHECK(hipEventCreate(&ctx->ev_start));
+    PTC_HIP_CHECK(hipEventCreate(&ctx->ev_stop));
+    PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = ctx;
+    return PTC_OK;
+}
+
+void ptc_context_destroy(ptc_context *ctx)
+{
+    if (!ctx)
+    {
+        return;
+    }
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_stats);
+    (void)hipFree(ctx->wf_buf);
+    (void)hipEventDestroy(ctx->ev_start);
+    (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream)
+    {
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+int ptc_context_set_stream(ptc_context *ctx, void *hip_stream)
+{
+    if (!ctx)
+    {
+        set_error("ptc_context_set_stream: ctx is NULL");
+        return PTC_E_INVALID;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream)
+    {
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->own_stream = false;
+    }
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return PTC_OK;
+}
+
+int ptc_synchronize(ptc_context *ctx)
+{
+    if (!ctx)
+    {
+        set_error("ptc_synchronize: ctx is NULL");
+        return PTC_E_INVALID;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PTC_OK;
+}
+
+int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_meshes,
+                     const ptc_instance_desc *instances, uint32_t n_instances,
+                     const ptc_envmap_desc *envmap, const ptc_build_options *opts, ptc_scene **out)
+{
+    if (!ctx || !out || (n_meshes && !meshes) || (n_instances && !instances))
+    {
+        set_error("ptc_scene_create: NULL argument");
+        return PTC_E_INVALID;
+    }
+    *out = nullptr;
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    // validate and lay the meshes out back to back
+    std::vector<uint32_t> vtx_off(n_meshes + 1, 0), tri_off(n_meshes + 1, 0);
+    for (uint32_t m = 0; m < n_meshes; ++m)
+    {
+        const ptc_mesh_desc &M = meshes[m];
+        if ((M.n_vertices && (!M.positions || !M.normals)) || (M.n_triangles && !M.indices))
+        {
+            set_error("ptc_scene_create: mesh with NULL arrays");
+            return PTC_E_INVALID;
+        }
+        for (size_t k = 0; k < 3 * (size_t)M.n_triangles; ++k)
+        {
+            if (M.indices[k] >= M.n_vertices)
+            {
+                set_error("ptc_scene_create: vertex index out of range");
+                return PTC_E_INVALID;
+            }
+        }
+        const uint64_t v = (uint64_t)vtx_off[m] + M.n_vertices, t = (uint64_t)tri_off[m] + M.n_triangles;
+        if (v > 0x7fffffffu || t > 0x7fffffffu)
+        {
+            set_error("ptc_scene_create: scene too large");
+            return PTC_E_LIMIT;
+        }
+        vtx_off[m + 1] = (uint32_t)v;
+        tri_off[m + 1] = (uint32_t)t;
+    }
+    std::vector<DInstance> inst(n_instances);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_instances; ++i)
+    {
+        const ptc_instance_desc &I = instances[i];
+        if (I.mesh >= n_meshes || I.kind > PTC_KIND_DIELECTRIC)
+        {
+            set_error("ptc_scene_create: instance with bad mesh index or material kind");
+            return PTC_E_INVALID;
+        }
+        DInstance &D = inst[i];
+        std::memset(&D, 0, sizeof D);
+        std::memcpy(D.o2w, I.transform, sizeof D.o2w);
+        inverse_affine(D.o2w, D.w2o);
+        D.kind = I.kind;
+        D.vtx_offset = vtx_off[I.mesh];
+        D.tri_offset = tri_off[I.mesh];
+        D.first_flat = (uint32_t)total;
+        D.n_tris = meshes[I.mesh].n_triangles;
+        total += D.n_tris;
+        if (total > 0x7ffffff0u)
+        {
+            set_error("ptc_scene_create: more than 2^31 flattened triangles");
+            return PTC_E_LIMIT;
+        }
+    }
+    if (envmap && envmap->rgba && (envmap->width == 0 || envmap->height == 0))
+    {
+        set_error("ptc_scene_create: empty environment map");
+        return PTC_E_INVALID;
+    }
+
+    ptc_scene *S = new (std::nothrow) ptc_scene();
+    if (!S)
+    {
+        set_error("out of host memory");
+        return PTC_E_NOMEM;
+    }
+    S->ctx = ctx;
+    int rc = PTC_OK;
+    auto fail = [&](int code) {
+        ptc_scene_destroy(S);
+        return code;
+    };
+    const size_t nv = vtx_off[n_meshes], nt = tri_off[n_meshes];
+    hipStream_t st = ctx->stream;
+#define PTC_TRY(expr)                                                                     \
+    do                                                                                    \
+    {                                                                                     \
+        const hipError_t err_ = (expr);                                                   \
+        if (err_ != hipSuccess)                                                           \
+        {                                                                                 \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(err_));               \
+            return fail(PTC_E_DEVICE);                                                    \
+        }                                                                                 \
+    } while (0)
+    PTC_TRY(hipMalloc(&S->d_positions, std::max<size_t>(nv, 1) * 12));
+    PTC_TRY(hipMalloc(&S->d_normals, std::max<size_t>(nv, 1) * 12));
+    PTC_TRY(hipMalloc(&S->d_indices, std::max<size_t>(nt, 1) * 12));
+    PTC_TRY(hipMalloc(&S->d_instances, std::max<size_t>(n_instances, 1) * sizeof(DInstance)));
+    for (uint32_t m = 0; m < n_meshes; ++m)
+    {
+        const ptc_mesh_desc &M = meshes[m];
+        if (M.n_vertices)
+        {
+            PTC_TRY(hipMemcpyAsync(S->d_positions + 3 * (size_t)vtx_off[m], M.positions,
+                                   (size_t)M.n_vertices * 12, hipMemcpyHostToDevice, st));
+            PTC_TRY(hipMemcpyAsync(S->d_normals + 3 * (size_t)vtx_off[m], M.normals,
+                                   (size_t)M.n_vertices * 12, hipMemcpyHostToDevice, st));
+        }
+        if (M.n_triangles)
+        {
+            PTC_TRY(hipMemcpyAsync(S->d_indices + 3 * (size_t)tri_off[m], M.indices,
+                                   (size_t)M.n_triangles * 12, hipMemcpyHostToDevice, st));
+        }
+    }
+    if (n_instances)
+    {
+        PTC_TRY(hipMemcpyAsync(S->d_instances, inst.data(), n_instances * sizeof(DInstance),
+                               hipMemcpyHostToDevice, st));
+    }
+    if (envmap && envmap->rgba)
+    {
+        const size_t eb = (size_t)envmap->width * envmap->height * 16;
+        PTC_TRY(hipMalloc(&S->d_env, eb));
+        PTC_TRY(hipMemcpyAsync(S->d_env, envmap->rgba, eb, hipMemcpyHostToDevice, st));
+        S->d.env = S->d_env;
+        S->d.env_w = envmap->width;
+        S->d.env_h = envmap->height;
+    }
+    PTC_TRY(hipStreamSynchronize(st)); // host arrays may be freed by the caller after return
+#undef PTC_TRY
+    S->d.positions = S->d_positions;
+    S->d.normals = S->d_normals;
+    S->d.indices = S->d_indices;
+    S->d.instances = S->d_instances;
+    S->d.n_instances = n_instances;
+    S->d.n_tris = (uint32_t)total;
+    S->info.n_triangles = (uint32_t)total;
+    S->info.n_instances = n_instances;
+
+    rc = build_bvh(ctx, S, inst, (uint32_t)total, opts ? opts->search_radius : 0u);
+    if (rc != PTC_OK)
+    {
+        return fail(rc);
+    }
+    S->info.device_bytes = (uint64_t)S->info.n_nodes * 80 + (uint64_t)total * 48 + nv * 24 + nt * 12 +
+                           n_instances * sizeof(DInstance) +
+                           (S->d_env ? (uint64_t)S->d.env_w * S->d.env_h * 16 : 0);
+    *out = S;
+    return PTC_OK;
+}
+
+void ptc_scene_destroy(ptc_scene *scene)
+{
+    if (!scene)
+    {
+        return;
+    }
+    (void)hipSetDevice(scene->ctx->device);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    (void)hipFree(scene->d_nodes);
+    (void)hipFree(scene->d_tris);
+    (void)hipFree(scene->d_positions);
+    (void)hipFree(scene->d_normals);
+    (void)hipFree(scene->d_indices);
+    (void)hipFree(scene->d_instances);
+    (void)hipFree(scene->d_env);
+    delete scene;
+}
+
+int ptc_scene_get_info(const ptc_scene *scene, ptc_scene_info *out)
+{
+    if (!scene || !out)
+    {
+        set_error("ptc_scene_get_info: NULL argument");
+        return PTC_E_INVALID;
+    }
+    *out = scene->info;
+    return PTC_OK;
+}
+
+int ptc_scene_read_bvh(const ptc_scene *scene, ptc_bvh8_node *nodes, size_t n_nodes,
+                       ptc_bvh_triangle *triangles, size_t n_triangles)
+{
+    if (!scene || !nodes || (!triangles && n_triangles))
+    {
+        set_error("ptc_scene_read_bvh: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (n_nodes != scene->info.n_nodes || n_triangles != scene->info.n_triangles)
+    {
+        set_error("ptc_scene_read_bvh: buffer sizes do not match ptc_scene_get_info");
+        return PTC_E_INVALID;
+    }
+    if (use_device(scene->ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    hipStream_t st = scene->ctx->stream;
+    PTC_HIP_CHECK(hipMemcpyAsync(nodes, scene->d_nodes, n_nodes * 80, hipMemcpyDeviceToHost, st));
+    if (n_triangles)
+    {
+        PTC_HIP_CHECK(hipMemcpyAsync(triangles, scene->d_tris, n_triangles * 48, hipMemcpyDeviceToHost, st));
+    }
+    PTC_HIP_CHECK(hipStreamSynchronize(st));
+    return PTC_OK;
+}
+
+int ptc_film_create(ptc_context *ctx, uint32_t width, uint32_t height, void *accum_dev,
+                    void *rgba8_dev, ptc_film **out)
+{
+    if (!ctx || !out || width == 0 || height == 0 || (uint64_t)width * height > 0x10000000u)
+    {
+        set_error("ptc_film_create: bad argument");
+        return PTC_E_INVALID;
+    }
+    *out = nullptr;
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    ptc_film *F = new (std::nothrow) ptc_film();
+    if (!F)
+    {
+        set_error("out of host memory");
+        return PTC_E_NOMEM;
+    }
+    F->ctx = ctx;
+    F->width = width;
+    F->height = height;
+    const size_t n = (size_t)width * height;
+    if (accum_dev)
+    {
+        F->d_accum = static_cast<float4 *>(accum_dev);
+    }
+    else
+    {
+        if (hipMalloc(&F->d_accum, n * 16) != hipSuccess)
+        {
+            set_error("ptc_film_create: hipMalloc failed");
+            delete F;
+            return PTC_E_NOMEM;
+        }
+        F->own_accum = true;
+        // draw_frame clears the storage image to (0,0,0,1) (src/renderer.cpp:2023-2048)
+        (void)hipMemsetAsync(F->d_accum, 0, n * 16, ctx->stream);
+    }
+    if (rgba8_dev)
+    {
+        F->d_rgba8 = static_cast<uint32_t *>(rgba8_dev);
+    }
+    else
+    {
+        if (hipMalloc(&F->d_rgba8, n * 4) != hipSuccess)
+        {
+            set_error("ptc_film_create: hipMalloc failed");
+            ptc_film_destroy(F);
+            return PTC_E_NOMEM;
+        }
+        F->own_rgba8 = true;
+        (void)hipMemsetAsync(F->d_rgba8, 0, n * 4, ctx->stream);
+    }
+    *out = F;
+    return PTC_OK;
+}
+
+void ptc_film_destroy(ptc_film *film)
+{
+    if (!film)
+    {
+        return;
+    }
+    (void)hipSetDevice(film->ctx->device);
+    (void)hipStreamSynchronize(film->ctx->stream);
+    if (film->own_accum)
+    {
+        (void)hipFree(film->d_accum);
+    }
+    if (film->own_rgba8)
+    {
+        (void)hipFree(film->d_rgba8);
+    }
+    delete film;
+}
+
+int ptc_film_reset(ptc_film *film)
+{
+    if (!film)
+    {
+        set_error("ptc_film_reset: film is NULL");
+        return PTC_E_INVALID;
+    }
+    film->sample_count = 0;
+    return PTC_OK;
+}
+
+uint32_t ptc_film_sample_count(const ptc_film *film)
+{
+    return film ? film->sample_count : 0u;
+}
+
+int ptc_film_set_sample_count(ptc_film *film, uint32_t sample_count)
+{
+    if (!film)
+    {
+        set_error("ptc_film_set_sample_count: film is NULL");
+        return PTC_E_INVALID;
+    }
+    film->sample_count = sample_count;
+    return PTC_OK;
+}
+
+int ptc_film_read_accum(ptc_film *film, float *rgba_out)
+{
+    if (!film || !rgba_out)
+    {
+        set_error("ptc_film_read_accum: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (use_device(film->ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    const size_t n = (size_t)film->width * film->height;
+    PTC_HIP_CHECK(hipMemcpyAsync(rgba_out, film->d_accum, n * 16, hipMemcpyDeviceToHost, film->ctx->stream));
+    PTC_HIP_CHECK(hipStreamSynchronize(film->ctx->stream));
+    return PTC_OK;
+}
+
+int ptc_film_read_rgba8(ptc_film *film, uint8_t *rgba_out)
+{
+    if (!film || !rgba_out)
+    {
+        set_error("ptc_film_read_rgba8: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (use_device(film->ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    const size_t n = (size_t)film->width * film->height;
+    PTC_HIP_CHECK(hipMemcpyAsync(rgba_out, film->d_rgba8, n * 4, hipMemcpyDeviceToHost, film->ctx->stream));
+    PTC_HIP_CHECK(hipStreamSynchronize(film->ctx->stream));
+    return PTC_OK;
+}
+
+void *ptc_film_accum_device_ptr(ptc_film *film)
+{
+    return film ? film->d_accum : nullptr;
+}
+
+int ptc_film_resolve(ptc_film *film, int sum_mode)
+{
+    if (!film)
+    {
+        set_error("ptc_film_resolve: film is NULL");
+        return PTC_E_INVALID;
+    }
+    if (use_device(film->ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    return launch_resolve(film->ctx, film, sum_mode);
+}
+
+int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const ptc_camera *camera,
+               const ptc_render_params *params)
+{
+    if (!ctx || !scene || !film || !camera || !params)
+    {
+        set_error("ptc_render: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (scene->ctx != ctx || film->ctx != ctx)
+    {
+        set_error("ptc_render: scene or film belongs to another context");
+        return PTC_E_INVALID;
+    }
+    if (params->samples_per_frame == 0 || params->n_frames == 0)
+    {
+        set_error("ptc_render: samples_per_frame and n_frames must be >= 1");
+        return PTC_E_INVALID;
+    }
+    if (params->integrator > PTC_INTEGRATOR_WAVEFRONT || params->accumulate > PTC_ACCUM_SUM)
+    {
+        set_error("ptc_render: unknown integrator or accumulation mode");
+        return PTC_E_INVALID;
+    }
+    const uint64_t added = (uint64_t)params->samples_per_frame * params->n_frames;
+    if ((uint64_t)film->sample_count + added > 0xffffffffull)
+    {
+        set_error("ptc_render: sample count overflow");
+        return PTC_E_LIMIT;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    DFrame F = make_frame(*camera, film->width, film->height);
+    F.global_frame_count = params->global_frame_count;
+    F.sample_count = film->sample_count;
+    F.samples_per_frame = params->samples_per_frame;
+    F.n_frames = params->n_frames;
+    F.frame_stride = params->frame_stride ? params->frame_stride : 1u;
+    F.max_depth = params->max_depth ? params->max_depth : 32u;
+    F.tmax = params->tmax > 0.0f ? params->tmax : 10000.0f;
+    F.accumulate_sum = params->accumulate == PTC_ACCUM_SUM ? 1u : 0u;
+    PTC_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
+    int rc;
+    if (params->integrator == PTC_INTEGRATOR_WAVEFRONT)
+    {
+        rc = launch_render_wavefront(ctx, scene, film, F);
+    }
+    else
+    {
+        rc = launch_render_mega(ctx, scene, film, F, false);
+    }
+    if (rc != PTC_OK)
+    {
+        return rc;
+    }
+    PTC_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
+    film->sample_count += (uint32_t)added;
+    return PTC_OK;
+}
+
+int ptc_primary_hits(ptc_context *ctx, const ptc_scene *scene, const ptc_camera *camera,
+                     uint32_t width, uint32_t height, uint32_t global_frame_count, float tmax,
+                     uint32_t *ids_out)
+{
+    if (!ctx || !scene || !camera || !ids_out || width == 0 || height == 0)
+    {
+        set_error("ptc_primary_hits: bad argument");
+        return PTC_E_INVALID;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    DFrame F = make_frame(*camera, width, height);
+    F.global_frame_count = global_frame_count;
+    F.tmax = tmax > 0.0f ? tmax : 10000.0f;
+    uint32_t *d_ids = nullptr;
+    const size_t n = (size_t)width * height;
+    PTC_HIP_CHECK(hipMalloc(&d_ids, n * 4));
+    int rc = launch_primary_hits(ctx, scene, F, d_ids);
+    if (rc == PTC_OK)
+    {
+        hipError_t e = hipMemcpyAsync(ids_out, d_ids, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+        {
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e != hipSuccess)
+        {
+            set_error(std::string("ptc_primary_hits: ") + hipGetErrorString(e));
+            rc = PTC_E_DEVICE;
+        }
+    }
+    (void)hipFree(d_ids);
+    return rc;
+}
+
+int ptc_trace_rays_device(ptc_context *ctx, const ptc_scene *scene, const void *rays_dev, size_t n_rays,
+                          float tmax, void *hits_dev)
+{
+    if (!ctx || !scene || (n_rays && (!rays_dev || !hits_dev)))
+    {
+        set_error("ptc_trace_rays_device: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (n_rays > 0x7fffffffull * 128)
+    {
+        set_error("ptc_trace_rays_device: too many rays for one launch");
+        return PTC_E_LIMIT;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    return launch_trace(ctx, scene, static_cast<const float *>(rays_dev), n_rays,
+                        tmax > 0.0f ? tmax : 10000.0f, static_cast<ptc_hit *>(hits_dev), false);
+}
+
+int ptc_trace_rays(ptc_context *ctx, const ptc_scene *scene, const float *rays, size_t n_rays,
+                   float tmax, ptc_hit *hits_out, ptc_stats *counters)
+{
+    if (!ctx || !scene || (n_rays && (!rays || !hits_out)))
+    {
+        set_error("ptc_trace_rays: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (n_rays == 0)
+    {
+        return PTC_OK;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    float *d_rays = nullptr;
+    ptc_hit *d_hits = nullptr;
+    PTC_HIP_CHECK(hipMalloc(&d_rays, n_rays * 24));
+    if (hipMalloc(&d_hits, n_rays * sizeof(ptc_hit)) != hipSuccess)
+    {
+        (void)hipFree(d_rays);
+        set_error("ptc_trace_rays: hipMalloc failed");
+        return PTC_E_NOMEM;
+    }
+    hipStream_t st = ctx->stream;
+    int rc = PTC_OK;
+    DeviceStats before{}, after{};
+    hipError_t e = hipMemcpyAsync(d_rays, rays, n_rays * 24, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && counters)
+    {
+        e = hipMemcpyAsync(&before, ctx->d_stats, sizeof before, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess)
+    {
+        rc = launch_trace(ctx, scene, d_rays, n_rays, tmax > 0.0f ? tmax : 10000.0f, d_hits,
+                          counters != nullptr);
+    }
+    if (e == hipSuccess && rc == PTC_OK)
+    {
+        e = hipMemcpyAsync(hits_out, d_hits, n_rays * sizeof(ptc_hit), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess && rc == PTC_OK && counters)
+    {
+        e = hipMemcpyAsync(&after, ctx->d_stats, sizeof after, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess)
+    {
+        e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    if (e != hipSuccess)
+    {
+        set_error(std::string("ptc_trace_rays: ") + hipGetErrorString(e));
+        return PTC_E_DEVICE;
+    }
+    if (rc == PTC_OK && counters)
+    {
+        counters->rays += n_rays;
+        counters->nodes_visited += after.nodes - before.nodes;
+        counters->tris_tested += after.tris - before.tris;
+    }
+    return rc;
+}
+
+int ptc_get_stats(ptc_context *ctx, ptc_stats *out)
+{
+    if (!ctx || !out)
+    {
+        set_error("ptc_get_stats: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    DeviceStats s{};
+    PTC_HIP_CHECK(hipMemcpyAsync(&s, ctx->d_stats, sizeof s, hipMemcpyDeviceToHost, ctx->stream));
+    PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop) == hipSuccess)
+    {
+        ctx->last_render_ms = ms;
+    }
+    out->rays = s.rays;
+    out->paths = s.paths;
+    out->nodes_visited = s.nodes;
+    out->tris_tested = s.tris;
+    out->render_ms = ctx->last_render_ms;
+    return PTC_OK;
+}
+
+int ptc_reset_stats(ptc_context *ctx)
+{
+    if (!ctx)
+    {
+        set_error("ptc_reset_stats: ctx is NULL");
+        return PTC_E_INVALID;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    PTC_HIP_CHECK(hipMemsetAsync(ctx->d_stats, 0, sizeof(DeviceStats), ctx->stream));
+    return PTC_OK;
+}
+
+int ptc_write_png(ptc_film *film, const char *file_name)
+{
+    if (!film || !file_name)
+    {
+        set_error("ptc_write_png: NULL argument");
+        return PTC_E_INVALID;
+    }
+    std::vector<uint8_t> px((size_t)film->width * film->height * 4);
+    const int rc = ptc_film_read_rgba8(film, px.data());
+    if (rc != PTC_OK)
+    {
+        return rc;
+    }
+    if (!write_png_rgba8(file_name, px.data(), film->width, film->height))
+    {
+        // message text of write_png(), src/utility.cpp:101-105
+        set_error(std::string("Failed to write PNG image to \"") + file_name + "\"");
+        return PTC_E_IO;
+    }
+    return PTC_OK;
+}
+
+int ptc_math_eval(ptc_context *ctx, int fn, const float *a, const float *b, float *out, float *out2,
+                  size_t n)
+{
+    if (!ctx || !a || !b || !out || !out2)
+    {
+        set_error("ptc_math_eval: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (n == 0)
+    {
+        return PTC_OK;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    float *d = nullptr;
+    PTC_HIP_CHECK(hipMalloc(&d, n * 16));
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d, a, n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+    {
+        e = hipMemcpyAsync(d + n, b, n * 4, hipMemcpyHostToDevice, st);
+    }
+    int rc = PTC_OK;
+    if (e == hipSuccess)
+    {
+        rc = launch_math_eval(ctx, fn, d, d + n, d + 2 * n, d + 3 * n, n);
+    }
+    if (e == hipSuccess && rc == PTC_OK)
+    {
+        e = hipMemcpyAsync(out, d + 2 * n, n * 4, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess && rc == PTC_OK)
+    {
+        e = hipMemcpyAsync(out2, d + 3 * n, n * 4, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess)
+    {
+        e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess)
+    {
+        set_error(std::string("ptc_math_eval: ") + hipGetErrorString(e));
+        return PTC_E_DEVICE;
+    }
+    return rc;
+}
+
+} // extern "C"

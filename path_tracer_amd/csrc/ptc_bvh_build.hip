@@ -1,0 +1,900 @@
+// Wide-BVH builder for gfx950.
+//
+// Stands in for the driver-side acceleration-structure build that the
+// reference requests through vkCmdBuildAccelerationStructuresKHR
+// (src/renderer.cpp:1044-1142 BLAS, :1144-1281 TLAS; PreferFastTrace, opaque,
+// no culling). Instances are flattened: every (instance, primitive) becomes one
+// world-space triangle, so a single tree answers what the reference's
+// TLAS + BLAS pair answers.
+//
+// Pipeline, all on the device:
+//   1. flatten      world-space (v0, e1, e2) per triangle, padded AABB, scene bounds
+//   2. morton       63-bit Morton code of the AABB centre, radix sort (rocPRIM)
+//   3. ploc         binary tree by parallel locally-ordered clustering: every
+//                   round each cluster finds, within +-R neighbours along the
+//                   Morton curve, the partner whose merged box has the smallest
+//                   surface area; mutual choices merge. This is the agglomerative
+//                   form of the surface-area heuristic.
+//   4. collapse     top-down, one wide level per launch: open the child with the
+//                   largest surface area until 8 slots are used; subtrees of <= 3
+//                   triangles become leaf slots; children are placed in slots so
+//                   that (slot XOR ray octant) orders them front to back
+//   5. quantise     child boxes to 8 bits on a per-node power-of-two grid,
+//                   rounded outward against the float decode the traversal uses
+#include <string.h>
+
+#include "ptc_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ptc
+{
+namespace
+{
+
+constexpr int kBlock = 256;
+constexpr int kMaxRadius = 32;
+constexpr uint32_t kLeafMax = 3;
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    const uint32_t u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        v = fmin_(v, __shfl_xor(v, off, 64));
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        v = fmax_(v, __shfl_xor(v, off, 64));
+    }
+    return v;
+}
+
+// ---- 1. flatten -------------------------------------------------------------
+
+__global__ void __launch_bounds__(kBlock)
+k_flatten(const DInstance *__restrict__ inst, uint32_t n_inst,
+          const float *__restrict__ positions, const uint32_t *__restrict__ indices,
+          uint32_t n_flat, float4 *__restrict__ tri_tmp, float4 *__restrict__ box_lo,
+          float4 *__restrict__ box_hi, uint32_t *__restrict__ bounds)
+{
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    float lx = INFINITY, ly = INFINITY, lz = INFINITY;
+    float hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+    if (g < n_flat)
+    {
+        uint32_t lo = 0, hi = n_inst - 1;
+        while (lo < hi)
+        {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (inst[mid].first_flat <= g)
+            {
+                lo = mid;
+            }
+            else
+            {
+                hi = mid - 1;
+            }
+        }
+        const DInstance *__restrict__ I = &inst[lo];
+        const uint32_t prim = g - I->first_flat;
+        const uint32_t *__restrict__ idx = indices + 3u * (size_t)(I->tri_offset + prim);
+        const vec3 a = xform_point(I->o2w, load3(positions + 3u * (size_t)(idx[0] + I->vtx_offset)));
+        const vec3 b = xform_point(I->o2w, load3(positions + 3u * (size_t)(idx[1] + I->vtx_offset)));
+        const vec3 c = xform_point(I->o2w, load3(positions + 3u * (size_t)(idx[2] + I->vtx_offset)));
+        const vec3 e1 = b - a;
+        const vec3 e2 = c - a;
+        tri_tmp[3u * (size_t)g + 0] = make_float4(a.x, a.y, a.z, __uint_as_float(lo));
+        tri_tmp[3u * (size_t)g + 1] = make_float4(e1.x, e1.y, e1.z, __uint_as_float(prim));
+        tri_tmp[3u * (size_t)g + 2] = make_float4(e2.x, e2.y, e2.z, __uint_as_float(g));
+        lx = fmin_(a.x, fmin_(b.x, c.x));
+        ly = fmin_(a.y, fmin_(b.y, c.y));
+        lz = fmin_(a.z, fmin_(b.z, c.z));
+        hx = fmax_(a.x, fmax_(b.x, c.x));
+        hy = fmax_(a.y, fmax_(b.y, c.y));
+        hz = fmax_(a.z, fmax_(b.z, c.z));
+        box_lo[g] = make_float4(lx, ly, lz, 0.0f);
+        box_hi[g] = make_float4(hx, hy, hz, 0.0f);
+    }
+    lx = wave_min(lx);
+    ly = wave_min(ly);
+    lz = wave_min(lz);
+    hx = wave_max(hx);
+    hy = wave_max(hy);
+    hz = wave_max(hz);
+    if ((threadIdx.x & 63) == 0 && lx <= hx)
+    {
+        atomicMin(&bounds[0], f2ord(lx));
+        atomicMin(&bounds[1], f2ord(ly));
+        atomicMin(&bounds[2], f2ord(lz));
+        atomicMax(&bounds[3], f2ord(hx));
+        atomicMax(&bounds[4], f2ord(hy));
+        atomicMax(&bounds[5], f2ord(hz));
+    }
+}
+
+// ---- 2. pad boxes, Morton keys ----------------------------------------------
+
+__device__ __forceinline__ unsigned long long expand21(uint32_t v)
+{
+    unsigned long long x = v & 0x1fffffu;
+    x = (x | (x << 32)) & 0x1f00000000ffffULL;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffULL;
+    x = (x | (x << 8)) & 0x100f00f00f00f00fULL;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ULL;
+    x = (x | (x << 2)) & 0x1249249249249249ULL;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t quant21(float c, float lo, float hi)
+{
+    const float ext = hi - lo;
+    if (!(ext > 0.0f))
+    {
+        return 0u;
+    }
+    float t = (c - lo) / ext * 2097152.0f;
+    t = fmax_(0.0f, fmin_(t, 2097151.0f));
+    return (uint32_t)t;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_morton(uint32_t n, float4 *__restrict__ box_lo, float4 *__restrict__ box_hi,
+         const uint32_t *__restrict__ bounds, unsigned long long *__restrict__ keys,
+         uint32_t *__restrict__ vals)
+{
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n)
+    {
+        return;
+    }
+    const float slx = ord2f(bounds[0]), sly = ord2f(bounds[1]), slz = ord2f(bounds[2]);
+    const float shx = ord2f(bounds[3]), shy = ord2f(bounds[4]), shz = ord2f(bounds[5]);
+    float mag = fmax_(__builtin_fabsf(slx), __builtin_fabsf(shx));
+    mag = fmax_(mag, fmax_(__builtin_fabsf(sly), __builtin_fabsf(shy)));
+    mag = fmax_(mag, fmax_(__builtin_fabsf(slz), __builtin_fabsf(shz)));
+    // absolute padding that covers the rounding slop of the triangle test
+    const float pad = mag * (1.0f / 262144.0f);
+    float4 lo = box_lo[g], hi = box_hi[g];
+    const float cx = 0.5f * (lo.x + hi.x), cy = 0.5f * (lo.y + hi.y), cz = 0.5f * (lo.z + hi.z);
+    lo.x -= pad;
+    lo.y -= pad;
+    lo.z -= pad;
+    hi.x += pad;
+    hi.y += pad;
+    hi.z += pad;
+    box_lo[g] = lo;
+    box_hi[g] = hi;
+    const unsigned long long key = (expand21(quant21(cx, slx, shx)) << 2) |
+                                   (expand21(quant21(cy, sly, shy)) << 1) |
+                                   expand21(quant21(cz, slz, shz));
+    keys[g] = key;
+    vals[g] = g;
+}
+
+// ---- 3. PLOC ------------------------------------------------------------------
+// Binary nodes: ids [0, n) are leaves in Morton order, ids >= n are internal.
+// node_lo[id] = (box min, subtree triangle count as bits)
+// node_hi[id] = (box max, flat triangle index as bits for leaves)
+// node_lr[id - n] = (left, right) for internal nodes
+
+__global__ void __launch_bounds__(kBlock)
+k_init_clusters(uint32_t n, const uint32_t *__restrict__ sorted_vals,
+                const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi,
+                float4 *__restrict__ node_lo, float4 *__restrict__ node_hi,
+                uint32_t *__restrict__ cl_id, float4 *__restrict__ cl_lo,
+                float4 *__restrict__ cl_hi)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    const uint32_t p = sorted_vals[i];
+    float4 lo = box_lo[p], hi = box_hi[p];
+    lo.w = __uint_as_float(1u);
+    hi.w = __uint_as_float(p);
+    node_lo[i] = lo;
+    node_hi[i] = hi;
+    cl_id[i] = i;
+    cl_lo[i] = lo;
+    cl_hi[i] = hi;
+}
+
+__device__ __forceinline__ float merged_half_area(float4 alo, float4 ahi, float4 blo, float4 bhi)
+{
+    const float dx = fmax_(ahi.x, bhi.x) - fmin_(alo.x, blo.x);
+    const float dy = fmax_(ahi.y, bhi.y) - fmin_(alo.y, blo.y);
+    const float dz = fmax_(ahi.z, bhi.z) - fmin_(alo.z, blo.z);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_nearest(uint32_t n, int radius, const float4 *__restrict__ cl_lo,
+          const float4 *__restrict__ cl_hi, int *__restrict__ nn)
+{
+    __shared__ float4 s_lo[kBlock + 2 * kMaxRadius];
+    __shared__ float4 s_hi[kBlock + 2 * kMaxRadius];
+    const long long base = (long long)blockIdx.x * kBlock - radius;
+    for (int t = threadIdx.x; t < kBlock + 2 * radius; t += kBlock)
+    {
+        const long long j = base + t;
+        if (j >= 0 && j < (long long)n)
+        {
+            s_lo[t] = cl_lo[j];
+            s_hi[t] = cl_hi[j];
+        }
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    const int me = threadIdx.x + radius;
+    const float4 mlo = s_lo[me], mhi = s_hi[me];
+    float best = INFINITY;
+    int best_j = -1;
+    for (int off = -radius; off <= radius; ++off)
+    {
+        const long long j = (long long)i + off;
+        if (off == 0 || j < 0 || j >= (long long)n)
+        {
+            continue;
+        }
+        const float a = merged_half_area(mlo, mhi, s_lo[me + off], s_hi[me + off]);
+        if (a < best)
+        {
+            best = a;
+            best_j = (int)j;
+        }
+    }
+    nn[i] = best_j;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_merge_flags(uint32_t n, const int *__restrict__ nn, unsigned long long *__restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    const int j = nn[i];
+    const bool mutual = j >= 0 && nn[j] == (int)i;
+    const bool merge = mutual && (int)i < j;
+    const bool valid = !mutual || merge;
+    flags[i] = ((unsigned long long)(merge ? 1u : 0u) << 32) | (valid ? 1u : 0u);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_merge_emit(uint32_t n, uint32_t n_leaves, uint32_t next_node, const int *__restrict__ nn,
+             const unsigned long long *__restrict__ flags,
+             const unsigned long long *__restrict__ scan, const uint32_t *__restrict__ in_id,
+             const float4 *__restrict__ in_lo, const float4 *__restrict__ in_hi,
+             uint32_t *__restrict__ out_id, float4 *__restrict__ out_lo,
+             float4 *__restrict__ out_hi, float4 *__restrict__ node_lo,
+             float4 *__restrict__ node_hi, uint2 *__restrict__ node_lr,
+             uint32_t *__restrict__ totals)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    const unsigned long long f = flags[i], s = scan[i];
+    if (i == n - 1)
+    {
+        totals[0] = (uint32_t)(s & 0xffffffffu) + (uint32_t)(f & 0xffffffffu); // clusters left
+        totals[1] = (uint32_t)(s >> 32) + (uint32_t)(f >> 32);                 // merges done
+    }
+    if (!(f & 1u))
+    {
+        return;
+    }
+    const uint32_t pos = (uint32_t)(s & 0xffffffffu);
+    if (f >> 32)
+    {
+        const int j = nn[i];
+        const float4 alo = in_lo[i], ahi = in_hi[i], blo = in_lo[j], bhi = in_hi[j];
+        const uint32_t id = next_node + (uint32_t)(s >> 32);
+        float4 lo, hi;
+        lo.x = fmin_(alo.x, blo.x);
+        lo.y = fmin_(alo.y, blo.y);
+        lo.z = fmin_(alo.z, blo.z);
+        hi.x = fmax_(ahi.x, bhi.x);
+        hi.y = fmax_(ahi.y, bhi.y);
+        hi.z = fmax_(ahi.z, bhi.z);
+        lo.w = __uint_as_float(__float_as_uint(alo.w) + __float_as_uint(blo.w));
+        hi.w = 0.0f;
+        node_lo[id] = lo;
+        node_hi[id] = hi;
+        node_lr[id - n_leaves] = make_uint2(in_id[i], in_id[j]);
+        out_id[pos] = id;
+        out_lo[pos] = lo;
+        out_hi[pos] = hi;
+    }
+    else
+    {
+        out_id[pos] = in_id[i];
+        out_lo[pos] = in_lo[i];
+        out_hi[pos] = in_hi[i];
+    }
+}
+
+// ---- 4./5. collapse to 8-wide nodes, quantise ---------------------------------
+
+__device__ __forceinline__ float half_area(float4 lo, float4 hi)
+{
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// For every wide node of the current level: pick its (up to 8) children among
+// the binary subtree below wide_root[w], count internal children and leaf
+// triangles.
+__global__ void __launch_bounds__(kBlock)
+k_wide_select(uint32_t level_start, uint32_t level_end, uint32_t n_leaves,
+              const uint32_t *__restrict__ wide_root, const float4 *__restrict__ node_lo,
+              const float4 *__restrict__ node_hi, const uint2 *__restrict__ node_lr,
+              uint32_t *__restrict__ sel_child, uint32_t *__restrict__ sel_n,
+              unsigned long long *__restrict__ counts)
+{
+    const uint32_t w = level_start + blockIdx.x * kBlock + threadIdx.x;
+    if (w >= level_end)
+    {
+        return;
+    }
+    uint32_t child[8];
+    float area[8];
+    uint32_t n;
+    const uint32_t b = wide_root[w];
+    if (b < n_leaves)
+    {
+        child[0] = b;
+        area[0] = -1.0f;
+        n = 1;
+    }
+    else
+    {
+        const uint2 lr = node_lr[b - n_leaves];
+        child[0] = lr.x;
+        child[1] = lr.y;
+        n = 2;
+        for (uint32_t k = 0; k < 2; ++k)
+        {
+            area[k] = child[k] < n_leaves ? -1.0f : half_area(node_lo[child[k]], node_hi[child[k]]);
+        }
+        while (n < 8)
+        {
+            int pick = -1;
+            float best = -1.0f;
+            for (uint32_t k = 0; k < n; ++k)
+            {
+                if (area[k] > best)
+                {
+                    best = area[k];
+                    pick = (int)k;
+                }
+            }
+            if (pick < 0)
+            {
+                break;
+            }
+            const uint2 lr2 = node_lr[child[pick] - n_leaves];
+            child[pick] = lr2.x;
+            child[n] = lr2.y;
+            area[pick] = lr2.x < n_leaves ? -1.0f : half_area(node_lo[lr2.x], node_hi[lr2.x]);
+            area[n] = lr2.y < n_leaves ? -1.0f : half_area(node_lo[lr2.y], node_hi[lr2.y]);
+            ++n;
+        }
+    }
+    uint32_t ni = 0, nt = 0;
+    for (uint32_t k = 0; k < 8; ++k)
+    {
+        uint32_t c = 0xffffffffu;
+        if (k < n)
+        {
+            c = child[k];
+            const uint32_t cnt = __float_as_uint(node_lo[c].w);
+            if (cnt > kLeafMax)
+            {
+                ++ni;
+            }
+            else
+            {
+                nt += cnt;
+            }
+        }
+        sel_child[8u * (size_t)w + k] = c;
+    }
+    sel_n[w] = n;
+    counts[w - level_start] = ((unsigned long long)ni << 32) | nt;
+}
+
+__device__ __forceinline__ uint32_t ceil_pow2_exp(float ext)
+{
+    // exponent byte e with 2^(e-127) * 255 >= ext (checked again by the caller)
+    const float s = ext / 255.0f;
+    const uint32_t bits = __float_as_uint(s);
+    uint32_t e = (bits >> 23) & 0xffu;
+    if (bits & 0x7fffffu)
+    {
+        e += 1u;
+    }
+    return e < 1u ? 1u : (e > 254u ? 254u : e);
+}
+
+__device__ __forceinline__ int quant_lo(float v, float org, float scale)
+{
+    int q = (int)__builtin_floorf((v - org) / scale);
+    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+    while (q > 0 && __builtin_fmaf((float)q, scale, org) > v)
+    {
+        --q;
+    }
+    return q;
+}
+__device__ __forceinline__ int quant_hi(float v, float org, float scale)
+{
+    int q = (int)__builtin_ceilf((v - org) / scale);
+    q = q < 0 ? 0 : (q > 256 ? 256 : q);
+    while (q <= 255 && __builtin_fmaf((float)q, scale, org) < v)
+    {
+        ++q;
+    }
+    return q; // 256 = does not fit
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_wide_emit(uint32_t level_start, uint32_t level_end, uint32_t n_leaves, uint32_t child_alloc,
+            uint32_t tri_alloc, const unsigned long long *__restrict__ scan,
+            const uint32_t *__restrict__ sel_child, const uint32_t *__restrict__ sel_n,
+            const float4 *__restrict__ node_lo, const float4 *__restrict__ node_hi,
+            const uint2 *__restrict__ node_lr, const float4 *__restrict__ tri_tmp,
+            uint32_t *__restrict__ wide_root, uint4 *__restrict__ nodes_out,
+            float4 *__restrict__ tris_out, double *__restrict__ cost_sum)
+{
+    const uint32_t w = level_start + blockIdx.x * kBlock + threadIdx.x;
+    if (w >= level_end)
+    {
+        return;
+    }
+    const unsigned long long sc = scan[w - level_start];
+    const uint32_t child_base = child_alloc + (uint32_t)(sc >> 32);
+    const uint32_t tri_base = tri_alloc + (uint32_t)(sc & 0xffffffffu);
+    const uint32_t n = sel_n[w];
+
+    uint32_t child[8];
+    float4 clo[8], chi[8];
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+    float4 hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+    for (uint32_t k = 0; k < 8; ++k)
+    {
+        child[k] = sel_child[8u * (size_t)w + k];
+        if (k < n)
+        {
+            clo[k] = node_lo[child[k]];
+            chi[k] = node_hi[child[k]];
+            lo.x = fmin_(lo.x, clo[k].x);
+            lo.y = fmin_(lo.y, clo[k].y);
+            lo.z = fmin_(lo.z, clo[k].z);
+            hi.x = fmax_(hi.x, chi[k].x);
+            hi.y = fmax_(hi.y, chi[k].y);
+            hi.z = fmax_(hi.z, chi[k].z);
+        }
+    }
+    if (n == 0)
+    {
+        lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        hi = lo;
+    }
+
+    // slot assignment: slot s should hold the child lying furthest towards
+    // +axis where bit(axis) of s is set and towards -axis where it is clear,
+    // so that rays of octant o meet slots in decreasing (s ^ (7 - o)) order
+    const float ncx = 0.5f * (lo.x + hi.x), ncy = 0.5f * (lo.y + hi.y), ncz = 0.5f * (lo.z + hi.z);
+    int slot_of[8];
+    int child_in_slot[8];
+    for (int k = 0; k < 8; ++k)
+    {
+        slot_of[k] = -1;
+        child_in_slot[k] = -1;
+    }
+    for (uint32_t round = 0; round < n; ++round)
+    {
+        float best = -INFINITY;
+        int bc = -1, bs = -1;
+        for (uint32_t k = 0; k < n; ++k)
+        {
+            if (slot_of[k] >= 0)
+            {
+                continue;
+            }
+            const float dx = 0.5f * (clo[k].x + chi[k].x) - ncx;
+            const float dy = 0.5f * (clo[k].y + chi[k].y) - ncy;
+            const float dz = 0.5f * (clo[k].z + chi[k].z) - ncz;
+            for (int s = 0; s < 8; ++s)
+            {
+                if (child_in_slot[s] >= 0)
+                {
+                    continue;
+                }
+                const float score = ((s & 1) ? dx : -dx) + ((s & 2) ? dy : -dy) + ((s & 4) ? dz : -dz);
+                if (score > best)
+                {
+                    best = score;
+                    bc = (int)k;
+                    bs = s;
+                }
+            }
+        }
+        slot_of[bc] = bs;
+        child_in_slot[bs] = bc;
+    }
+
+    // per-axis power-of-two grid
+    uint32_t ex = ceil_pow2_exp(hi.x - lo.x);
+    uint32_t ey = ceil_pow2_exp(hi.y - lo.y);
+    uint32_t ez = ceil_pow2_exp(hi.z - lo.z);
+    uint32_t qlo[3][8], qhi[3][8];
+    for (int attempt = 0; attempt < 4; ++attempt)
+    {
+        const float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23),
+                    sz = __uint_as_float(ez << 23);
+        bool okx = true, oky = true, okz = true;
+        for (int s = 0; s < 8; ++s)
+        {
+            const int k = child_in_slot[s];
+            if (k < 0)
+            {
+                qlo[0][s] = qlo[1][s] = qlo[2][s] = 0u;
+                qhi[0][s] = qhi[1][s] = qhi[2][s] = 0u;
+                continue;
+            }
+            const int hx = quant_hi(chi[k].x, lo.x, sx), hy = quant_hi(chi[k].y, lo.y, sy),
+                      hz = quant_hi(chi[k].z, lo.z, sz);
+            okx = okx && hx <= 255;
+            oky = oky && hy <= 255;
+            okz = okz && hz <= 255;
+            qlo[0][s] = (uint32_t)quant_lo(clo[k].x, lo.x, sx);
+            qlo[1][s] = (uint32_t)quant_lo(clo[k].y, lo.y, sy);
+            qlo[2][s] = (uint32_t)quant_lo(clo[k].z, lo.z, sz);
+            qhi[0][s] = (uint32_t)(hx > 255 ? 255 : hx);
+            qhi[1][s] = (uint32_t)(hy > 255 ? 255 : hy);
+            qhi[2][s] = (uint32_t)(hz > 255 ? 255 : hz);
+        }
+        if (okx && oky && okz)
+        {
+            break;
+        }
+        ex += okx ? 0u : 1u;
+        ey += oky ? 0u : 1u;
+        ez += okz ? 0u : 1u;
+    }
+
+    // slots in order: meta, internal children ranks, leaf triangles
+    uint32_t imask = 0u, meta[8];
+    uint32_t rank = 0u, toff = 0u;
+    float cost = 0.0f;
+    const float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23),
+                sz = __uint_as_float(ez << 23);
+    for (int s = 0; s < 8; ++s)
+    {
+        meta[s] = 0u;
+        const int k = child_in_slot[s];
+        if (k < 0)
+        {
+            continue;
+        }
+        const float bx = (float)(qhi[0][s] - qlo[0][s]) * sx, by = (float)(qhi[1][s] - qlo[1][s]) * sy,
+                    bz = (float)(qhi[2][s] - qlo[2][s]) * sz;
+        const float a = bx * by + by * bz + bz * bx;
+        const uint32_t c = child[k];
+        const uint32_t cnt = __float_as_uint(clo[k].w);
+        if (cnt > kLeafMax)
+        {
+            imask |= 1u << s;
+            meta[s] = 0x20u | (24u + (uint32_t)s);
+            wide_root[child_base + rank] = c;
+            ++rank;
+            cost += a;
+        }
+        else
+        {
+            meta[s] = (((1u << cnt) - 1u) << 5) | toff;
+            // gather the <= 3 triangles below c, left to right
+            uint32_t stack[4];
+            int sp = 0;
+            stack[sp++] = c;
+            while (sp)
+            {
+                const uint32_t id = stack[--sp];
+                if (id < n_leaves)
+                {
+                    const uint32_t p = __float_as_uint(node_hi[id].w);
+                    float4 *__restrict__ dst = tris_out + 3u * (size_t)(tri_base + toff);
+                    dst[0] = tri_tmp[3u * (size_t)p + 0];
+                    dst[1] = tri_tmp[3u * (size_t)p + 1];
+                    dst[2] = tri_tmp[3u * (size_t)p + 2];
+                    ++toff;
+                }
+                else
+                {
+                    const uint2 lr = node_lr[id - n_leaves];
+                    stack[sp++] = lr.y;
+                    stack[sp++] = lr.x;
+                }
+            }
+            cost += a * (float)cnt;
+        }
+    }
+
+    uint4 w0, w1, w2, w3, w4;
+    w0.x = __float_as_uint(lo.x);
+    w0.y = __float_as_uint(lo.y);
+    w0.z = __float_as_uint(lo.z);
+    w0.w = ex | (ey << 8) | (ez << 16) | (imask << 24);
+    w1.x = child_base;
+    w1.y = tri_base;
+    w1.z = meta[0] | (meta[1] << 8) | (meta[2] << 16) | (meta[3] << 24);
+    w1.w = meta[4] | (meta[5] << 8) | (meta[6] << 16) | (meta[7] << 24);
+#define PTC_PACK4(a, o) ((a)[o] | ((a)[(o) + 1] << 8) | ((a)[(o) + 2] << 16) | ((a)[(o) + 3] << 24))
+    w2.x = PTC_PACK4(qlo[0], 0);
+    w2.y = PTC_PACK4(qlo[0], 4);
+    w2.z = PTC_PACK4(qlo[1], 0);
+    w2.w = PTC_PACK4(qlo[1], 4);
+    w3.x = PTC_PACK4(qlo[2], 0);
+    w3.y = PTC_PACK4(qlo[2], 4);
+    w3.z = PTC_PACK4(qhi[0], 0);
+    w3.w = PTC_PACK4(qhi[0], 4);
+    w4.x = PTC_PACK4(qhi[1], 0);
+    w4.y = PTC_PACK4(qhi[1], 4);
+    w4.z = PTC_PACK4(qhi[2], 0);
+    w4.w = PTC_PACK4(qhi[2], 4);
+#undef PTC_PACK4
+    uint4 *__restrict__ out = nodes_out + 5u * (size_t)w;
+    out[0] = w0;
+    out[1] = w1;
+    out[2] = w2;
+    out[3] = w3;
+    out[4] = w4;
+    atomicAdd(cost_sum, (double)cost);
+}
+
+struct TempPool
+{
+    std::vector<void *> ptrs;
+    ~TempPool()
+    {
+        for (void *p : ptrs)
+        {
+            (void)hipFree(p);
+        }
+    }
+    template <typename T> hipError_t alloc(T **out, size_t count)
+    {
+        void *p = nullptr;
+        const hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess)
+        {
+            ptrs.push_back(p);
+            *out = static_cast<T *>(p);
+        }
+        return e;
+    }
+};
+
+inline uint32_t blocks_for(size_t n)
+{
+    return (uint32_t)((n + kBlock - 1) / kBlock);
+}
+
+} // namespace
+
+int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &instances,
+              uint32_t n, uint32_t search_radius)
+{
+    hipStream_t st = ctx->stream;
+    const int radius = (int)std::min<uint32_t>(search_radius ? search_radius : 16u, kMaxRadius);
+    TempPool pool;
+
+    // outputs
+    const size_t node_cap = std::max<size_t>(n, 1);
+    uint4 *nodes_tmp = nullptr;
+    PTC_HIP_CHECK(pool.alloc(&nodes_tmp, node_cap * 5));
+    PTC_HIP_CHECK(hipMalloc(&scene->d_tris, std::max<size_t>(n, 1) * 48));
+    double *d_cost = nullptr;
+    PTC_HIP_CHECK(pool.alloc(&d_cost, 1));
+    PTC_HIP_CHECK(hipMemsetAsync(d_cost, 0, sizeof(double), st));
+
+    hipEvent_t e0, e1;
+    PTC_HIP_CHECK(hipEventCreate(&e0));
+    PTC_HIP_CHECK(hipEventCreate(&e1));
+    PTC_HIP_CHECK(hipEventRecord(e0, st));
+
+    uint32_t n_nodes = 1, depth = 1;
+    double root_half_area = 0.0;
+    if (n == 0)
+    {
+        PTC_HIP_CHECK(hipMemsetAsync(nodes_tmp, 0, 80, st));
+    }
+    else
+    {
+        float4 *tri_tmp, *box_lo, *box_hi, *node_lo, *node_hi, *cl_lo[2], *cl_hi[2];
+        uint32_t *bounds, *vals_in, *vals_out, *cl_id[2], *wide_root, *sel_child, *sel_n, *totals;
+        unsigned long long *keys_in, *keys_out, *flags, *scan;
+        uint2 *node_lr;
+        int *nn;
+        PTC_HIP_CHECK(pool.alloc(&tri_tmp, (size_t)n * 3));
+        PTC_HIP_CHECK(pool.alloc(&box_lo, n));
+        PTC_HIP_CHECK(pool.alloc(&box_hi, n));
+        PTC_HIP_CHECK(pool.alloc(&node_lo, 2 * (size_t)n));
+        PTC_HIP_CHECK(pool.alloc(&node_hi, 2 * (size_t)n));
+        PTC_HIP_CHECK(pool.alloc(&node_lr, n));
+        for (int k = 0; k < 2; ++k)
+        {
+            PTC_HIP_CHECK(pool.alloc(&cl_lo[k], n));
+            PTC_HIP_CHECK(pool.alloc(&cl_hi[k], n));
+            PTC_HIP_CHECK(pool.alloc(&cl_id[k], n));
+        }
+        PTC_HIP_CHECK(pool.alloc(&bounds, 8));
+        PTC_HIP_CHECK(pool.alloc(&totals, 2));
+        PTC_HIP_CHECK(pool.alloc(&vals_in, n));
+        PTC_HIP_CHECK(pool.alloc(&vals_out, n));
+        PTC_HIP_CHECK(pool.alloc(&keys_in, n));
+        PTC_HIP_CHECK(pool.alloc(&keys_out, n));
+        PTC_HIP_CHECK(pool.alloc(&flags, n));
+        PTC_HIP_CHECK(pool.alloc(&scan, n));
+        PTC_HIP_CHECK(pool.alloc(&nn, n));
+        PTC_HIP_CHECK(pool.alloc(&wide_root, node_cap));
+        PTC_HIP_CHECK(pool.alloc(&sel_child, node_cap * 8));
+        PTC_HIP_CHECK(pool.alloc(&sel_n, node_cap));
+
+        const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+        PTC_HIP_CHECK(hipMemcpyAsync(bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, st));
+
+        k_flatten<<<blocks_for(n), kBlock, 0, st>>>(scene->d_instances, (uint32_t)instances.size(),
+                                                   scene->d_positions, scene->d_indices, n, tri_tmp,
+                                                   box_lo, box_hi, bounds);
+        k_morton<<<blocks_for(n), kBlock, 0, st>>>(n, box_lo, box_hi, bounds, keys_in, vals_in);
+
+        size_t sort_bytes = 0, scan_bytes = 0;
+        PTC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_in, keys_out, vals_in,
+                                                vals_out, n, 0, 63, st));
+        PTC_HIP_CHECK(rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0ULL, n,
+                                              rocprim::plus<unsigned long long>(), st));
+        char *prim_tmp = nullptr;
+        const size_t prim_bytes = std::max(sort_bytes, scan_bytes);
+        PTC_HIP_CHECK(pool.alloc(&prim_tmp, prim_bytes));
+        size_t tmp_bytes = prim_bytes;
+        PTC_HIP_CHECK(rocprim::radix_sort_pairs(prim_tmp, tmp_bytes, keys_in, keys_out, vals_in,
+                                                vals_out, n, 0, 63, st));
+
+        k_init_clusters<<<blocks_for(n), kBlock, 0, st>>>(n, vals_out, box_lo, box_hi, node_lo, node_hi,
+                                                         cl_id[0], cl_lo[0], cl_hi[0]);
+
+        // PLOC rounds
+        uint32_t n_cl = n, next_node = n;
+        int cur = 0;
+        int rounds = 0;
+        while (n_cl > 1)
+        {
+            k_nearest<<<blocks_for(n_cl), kBlock, 0, st>>>(n_cl, radius, cl_lo[cur], cl_hi[cur], nn);
+            k_merge_flags<<<blocks_for(n_cl), kBlock, 0, st>>>(n_cl, nn, flags);
+            tmp_bytes = prim_bytes;
+            PTC_HIP_CHECK(rocprim::exclusive_scan(prim_tmp, tmp_bytes, flags, scan, 0ULL, n_cl,
+                                                  rocprim::plus<unsigned long long>(), st));
+            k_merge_emit<<<blocks_for(n_cl), kBlock, 0, st>>>(
+                n_cl, n, next_node, nn, flags, scan, cl_id[cur], cl_lo[cur], cl_hi[cur], cl_id[cur ^ 1],
+                cl_lo[cur ^ 1], cl_hi[cur ^ 1], node_lo, node_hi, node_lr, totals);
+            uint32_t h_tot[2];
+            PTC_HIP_CHECK(hipMemcpyAsync(h_tot, totals, sizeof h_tot, hipMemcpyDeviceToHost, st));
+            PTC_HIP_CHECK(hipStreamSynchronize(st));
+            if (h_tot[1] == 0 || h_tot[0] >= n_cl)
+            {
+                set_error("BVH build: clustering round made no progress");
+                return PTC_E_DEVICE;
+            }
+            n_cl = h_tot[0];
+            next_node += h_tot[1];
+            cur ^= 1;
+            if (++rounds > 4096)
+            {
+                set_error("BVH build: too many clustering rounds");
+                return PTC_E_DEVICE;
+            }
+        }
+        const uint32_t binary_root = n == 1 ? 0u : next_node - 1u;
+
+        // collapse, one wide level per pass
+        PTC_HIP_CHECK(hipMemcpyAsync(wide_root, &binary_root, 4, hipMemcpyHostToDevice, st));
+        {
+            float4 rl, rh;
+            PTC_HIP_CHECK(hipMemcpyAsync(&rl, node_lo + binary_root, 16, hipMemcpyDeviceToHost, st));
+            PTC_HIP_CHECK(hipMemcpyAsync(&rh, node_hi + binary_root, 16, hipMemcpyDeviceToHost, st));
+            PTC_HIP_CHECK(hipStreamSynchronize(st));
+            const double dx = (double)rh.x - rl.x, dy = (double)rh.y - rl.y, dz = (double)rh.z - rl.z;
+            root_half_area = dx * dy + dy * dz + dz * dx;
+        }
+        uint32_t level_start = 0, level_end = 1, tri_alloc = 0;
+        depth = 0;
+        while (level_start < level_end)
+        {
+            const uint32_t cnt = level_end - level_start;
+            k_wide_select<<<blocks_for(cnt), kBlock, 0, st>>>(level_start, level_end, n, wide_root, node_lo,
+                                                             node_hi, node_lr, sel_child, sel_n, flags);
+            tmp_bytes = prim_bytes;
+            PTC_HIP_CHECK(rocprim::exclusive_scan(prim_tmp, tmp_bytes, flags, scan, 0ULL, cnt,
+                                                  rocprim::plus<unsigned long long>(), st));
+            unsigned long long last_f = 0, last_s = 0;
+            PTC_HIP_CHECK(hipMemcpyAsync(&last_f, flags + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+            PTC_HIP_CHECK(hipMemcpyAsync(&last_s, scan + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+            PTC_HIP_CHECK(hipStreamSynchronize(st));
+            const uint32_t new_nodes = (uint32_t)((last_f + last_s) >> 32);
+            const uint32_t new_tris = (uint32_t)((last_f + last_s) & 0xffffffffu);
+            if ((size_t)level_end + new_nodes > node_cap || (size_t)tri_alloc + new_tris > n)
+            {
+                set_error("BVH build: node or triangle allocation overflow");
+                return PTC_E_DEVICE;
+            }
+            k_wide_emit<<<blocks_for(cnt), kBlock, 0, st>>>(
+                level_start, level_end, n, level_end, tri_alloc, scan, sel_child, sel_n, node_lo, node_hi,
+                node_lr, tri_tmp, wide_root, nodes_tmp, static_cast<float4 *>(scene->d_tris), d_cost);
+            tri_alloc += new_tris;
+            level_start = level_end;
+            level_end += new_nodes;
+            ++depth;
+        }
+        n_nodes = level_end;
+        if (tri_alloc != n)
+        {
+            set_error("BVH build: triangle count mismatch after collapse");
+            return PTC_E_DEVICE;
+        }
+    }
+
+    PTC_HIP_CHECK(hipMalloc(&scene->d_nodes, (size_t)n_nodes * 80));
+    PTC_HIP_CHECK(hipMemcpyAsync(scene->d_nodes, nodes_tmp, (size_t)n_nodes * 80, hipMemcpyDeviceToDevice, st));
+    double h_cost = 0.0;
+    PTC_HIP_CHECK(hipMemcpyAsync(&h_cost, d_cost, sizeof(double), hipMemcpyDeviceToHost, st));
+    PTC_HIP_CHECK(hipEventRecord(e1, st));
+    PTC_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0.0f;
+    PTC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+
+    if (depth > (uint32_t)(kLdsStack + kSpillStack - 4))
+    {
+        set_error("BVH build: wide tree deeper than the traversal stack");
+        return PTC_E_LIMIT;
+    }
+    scene->d.nodes = static_cast<const uint4 *>(scene->d_nodes);
+    scene->d.tris = static_cast<const float4 *>(scene->d_tris);
+    scene->info.n_nodes = n_nodes;
+    scene->info.bvh_depth = depth;
+    scene->info.build_ms = ms;
+    scene->info.sah_cost = root_half_area > 0.0 ? (float)(1.0 + h_cost / root_half_area) : 1.0f;
+    return PTC_OK;
+}
+
+} // namespace ptc

@@ -1,0 +1,672 @@
+// Device programs of the path tracer: RNG, camera rays, wide-BVH traversal with
+// Moller-Trumbore, the four material programs, the sky, the running-mean
+// accumulation and the tone map. Each function cites the reference shader it
+// stands in for (paths relative to the reference repository).
+#pragma once
+
+#include "ptc_device_math.h"
+
+namespace ptc
+{
+
+// ---- data resident in HBM ---------------------------------------------------
+
+struct DInstance // 128 bytes
+{
+    float o2w[12];      // object-to-world, 3x4 row-major
+    float w2o[12];      // inverse of o2w
+    uint32_t kind;      // PTC_KIND_*
+    uint32_t vtx_offset; // first vertex of the mesh in the shared vertex arrays
+    uint32_t tri_offset; // first triangle of the mesh in the shared index array
+    uint32_t first_flat; // flattened index of this instance's primitive 0
+    uint32_t n_tris;
+    uint32_t pad[3];
+};
+
+struct DScene
+{
+    const uint4 *__restrict__ nodes;   // 5 x uint4 per 80-byte node
+    const float4 *__restrict__ tris;   // 3 x float4 per 48-byte triangle
+    const float *__restrict__ positions; // 3 floats per vertex, all meshes
+    const float *__restrict__ normals;
+    const uint32_t *__restrict__ indices; // 3 per triangle, mesh-local vertex ids
+    const DInstance *__restrict__ instances;
+    const float4 *__restrict__ env; // RGBA32F equirect map or nullptr
+    uint32_t env_w, env_h;
+    uint32_t n_instances;
+    uint32_t n_tris;
+};
+
+// Push_constants of src/renderer.cpp:27-42 plus the build's explicit knobs.
+struct DFrame
+{
+    uint32_t global_frame_count;
+    uint32_t sample_count;
+    uint32_t samples_per_frame;
+    vec3 camera_position;
+    vec3 camera_dir_x;
+    vec3 camera_dir_y;
+    vec3 camera_dir_z;
+    float sensor_distance;
+    float sensor_half_width;
+    float sensor_half_height;
+    float focus_distance;
+    float aperture_radius;
+    uint32_t width, height;
+    uint32_t max_depth;
+    float tmax;
+    uint32_t n_frames;
+    uint32_t frame_stride;
+    uint32_t accumulate_sum;
+};
+
+struct Hit
+{
+    float t, u, v;
+    uint32_t flat;     // PTC_NO_HIT on a miss
+    uint32_t instance; // valid when flat != NO_HIT
+    uint32_t primitive;
+};
+
+constexpr uint32_t kNoHit = 0xffffffffu;
+
+// ---- RNG: shader_common.glsl:15-23, shader.rgen:34-42, :174-175 -------------
+
+PTC_DEV uint32_t hash_u32(uint32_t x)
+{
+    x += x << 10;
+    x ^= x >> 6;
+    x += x << 3;
+    x ^= x >> 11;
+    x += x << 15;
+    return x;
+}
+
+PTC_DEV float random_(uint32_t &s)
+{
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    // uint -> float rounds to nearest even, so this can return 1.0
+    return (float)s * (1.0f / 4294967296.0f);
+}
+
+PTC_DEV uint32_t seed_(uint32_t pixel_index, uint32_t global_frame_count)
+{
+    return hash_u32(pixel_index) + hash_u32(global_frame_count + 1u);
+}
+
+// ---- camera: shader.rgen:45-58, :181-191 ------------------------------------
+
+PTC_DEV void sample_gaussian(uint32_t &rng, float &gx, float &gy)
+{
+    const float float_min = 1.175494351e-38f;
+    const float r = __builtin_sqrtf(-2.0f * log_(fmax_(float_min, random_(rng))));
+    const float theta = kTwoPi * random_(rng);
+    float s, c;
+    sincos_(theta, s, c);
+    gx = r * c;
+    gy = r * s;
+}
+
+PTC_DEV void sample_disk(uint32_t &rng, float &dx, float &dy)
+{
+    const float r = __builtin_sqrtf(random_(rng));
+    const float theta = kTwoPi * random_(rng);
+    float s, c;
+    sincos_(theta, s, c);
+    dx = r * c;
+    dy = r * s;
+}
+
+PTC_DEV void camera_ray(const DFrame &f, uint32_t px, uint32_t py, uint32_t &rng,
+                        vec3 &origin, vec3 &dir)
+{
+    float gx, gy;
+    sample_gaussian(rng, gx, gy);
+    const float offx = 0.5f + 0.375f * gx;
+    const float offy = 0.5f + 0.375f * gy;
+    const float uvx = 2.0f * ((float)px + offx) / (float)f.width - 1.0f;
+    const float uvy = 2.0f * ((float)py + offy) / (float)f.height - 1.0f;
+    float dx, dy;
+    sample_disk(rng, dx, dy);
+    const float defx = f.aperture_radius * dx;
+    const float defy = f.aperture_radius * dy;
+    const vec3 defocus_offset = f.camera_dir_x * defx + f.camera_dir_y * defy;
+    origin = f.camera_position + defocus_offset;
+    vec3 t = f.camera_dir_z * f.sensor_distance;
+    t = t + (f.camera_dir_x * f.sensor_half_width) * uvx;
+    t = t + (f.camera_dir_y * f.sensor_half_height) * uvy;
+    t = t * f.focus_distance;
+    dir = normalize(t - defocus_offset);
+}
+
+// ---- closest-hit helpers: closest_hit_common.glsl ---------------------------
+
+PTC_DEV float offset_component(float p, float n)
+{
+    const int32_t of_i = (int32_t)(256.0f * n);
+    const uint32_t bits = __float_as_uint(p);
+    const uint32_t moved = (p < 0.0f) ? bits - (uint32_t)of_i : bits + (uint32_t)of_i;
+    const float p_i = __uint_as_float(moved);
+    const float origin = 1.0f / 32.0f;
+    const float float_scale = 1.0f / 65536.0f;
+    return __builtin_fabsf(p) < origin ? p + float_scale * n : p_i;
+}
+
+// closest_hit_common.glsl:25-44
+PTC_DEV vec3 offset_position_along_normal(vec3 p, vec3 n)
+{
+    return v3(offset_component(p.x, n.x), offset_component(p.y, n.y),
+              offset_component(p.z, n.z));
+}
+
+// closest_hit_common.glsl:46-52
+PTC_DEV vec3 sample_sphere(uint32_t &rng)
+{
+    const float theta = kTwoPi * random_(rng);
+    const float z = 2.0f * random_(rng) - 1.0f;
+    const float r = __builtin_sqrtf(1.0f - z * z);
+    float s, c;
+    sincos_(theta, s, c);
+    return v3(r * c, r * s, z);
+}
+
+// closest_hit_common.glsl:54-57
+PTC_DEV vec3 reflect_diffuse(vec3 normal, uint32_t &rng)
+{
+    return normalize(normal + sample_sphere(rng));
+}
+
+// Ray_payload of shader_common.glsl:4-13
+struct Payload
+{
+    vec3 color;
+    vec3 emissivity;
+    vec3 origin;
+    vec3 dir;
+    float attenuation;
+    uint32_t rng;
+    bool hit_sky;
+};
+
+// diffuse.rchit:5-14, specular.rchit:5-14, emissive.rchit:5-14,
+// dielectric.rchit:5-52, after get_hit() produced pos / nrm.
+PTC_DEV void material_scatter(uint32_t kind, vec3 dir, vec3 pos, vec3 nrm, Payload &P)
+{
+    P.hit_sky = false;
+    if (kind == 0u)
+    {
+        P.origin = offset_position_along_normal(pos, nrm);
+        P.dir = reflect_diffuse(nrm, P.rng);
+        P.color = v3((nrm.x + 1.0f) * 0.5f, (nrm.y + 1.0f) * 0.5f, (nrm.z + 1.0f) * 0.5f);
+        P.emissivity = v3(0.0f, 0.0f, 0.0f);
+    }
+    else if (kind == 1u)
+    {
+        P.origin = offset_position_along_normal(pos, nrm);
+        P.dir = reflect(dir, nrm);
+        P.color = v3(0.75f, 0.75f, 0.75f);
+        P.emissivity = v3(0.0f, 0.0f, 0.0f);
+    }
+    else if (kind == 2u)
+    {
+        P.origin = offset_position_along_normal(pos, nrm);
+        P.dir = reflect_diffuse(nrm, P.rng);
+        P.color = v3(0.75f, 0.75f, 0.75f);
+        P.emissivity = v3(5.0f, 5.0f, 5.0f);
+    }
+    else
+    {
+        P.color = v3(1.0f, 1.0f, 1.0f);
+        P.emissivity = v3(0.0f, 0.0f, 0.0f);
+        const bool into = dot(dir, nrm) < 0.0f;
+        const vec3 normal = into ? nrm : -nrm;
+        const vec3 reflected_dir = reflect(dir, normal);
+        const float n_air = 1.0f;
+        const float n_glass = 1.5f;
+        const float n_ratio = into ? n_air / n_glass : n_glass / n_air;
+        const float ddn = dot(dir, normal);
+        const float cos2t = 1.0f - n_ratio * n_ratio * (1.0f - ddn * ddn);
+        if (cos2t < 0.0f)
+        {
+            P.origin = offset_position_along_normal(pos, normal);
+            P.dir = reflected_dir;
+            return;
+        }
+        const float k = (into ? 1.0f : -1.0f) * (ddn * n_ratio + __builtin_sqrtf(cos2t));
+        const vec3 transmitted_dir = normalize(dir * n_ratio - nrm * k);
+        const float a = n_glass - n_air;
+        const float b = n_glass + n_air;
+        const float R0 = a * a / (b * b);
+        const float c = 1.0f - (into ? -ddn : dot(transmitted_dir, nrm));
+        const float Re = R0 + (1.0f - R0) * c * c * c * c * c;
+        const float Tr = 1.0f - Re;
+        const float Pr = 0.25f + 0.5f * Re;
+        const float RP = Re / Pr;
+        const float TP = Tr / (1.0f - Pr);
+        if (random_(P.rng) < Pr)
+        {
+            P.attenuation = RP;
+            P.origin = offset_position_along_normal(pos, normal);
+            P.dir = reflected_dir;
+        }
+        else
+        {
+            P.attenuation = TP;
+            P.origin = offset_position_along_normal(pos, -normal);
+            P.dir = transmitted_dir;
+        }
+    }
+}
+
+PTC_DEV vec3 load3(const float *__restrict__ p)
+{
+    return v3(p[0], p[1], p[2]);
+}
+
+// get_hit() of closest_hit_common.glsl:59-89 followed by the material program
+// selected by the instance's kind (the SBT record offset).
+PTC_DEV void closest_hit(const DScene &S, Payload &P, vec3 ray_dir, const Hit &h)
+{
+    const DInstance *__restrict__ I = &S.instances[h.instance];
+    const uint32_t *__restrict__ idx = S.indices + 3u * (size_t)(I->tri_offset + h.primitive);
+    const uint32_t i0 = idx[0] + I->vtx_offset;
+    const uint32_t i1 = idx[1] + I->vtx_offset;
+    const uint32_t i2 = idx[2] + I->vtx_offset;
+    const vec3 v0 = load3(S.positions + 3u * (size_t)i0);
+    const vec3 v1 = load3(S.positions + 3u * (size_t)i1);
+    const vec3 v2 = load3(S.positions + 3u * (size_t)i2);
+    const vec3 n0 = load3(S.normals + 3u * (size_t)i0);
+    const vec3 n1 = load3(S.normals + 3u * (size_t)i1);
+    const vec3 n2 = load3(S.normals + 3u * (size_t)i2);
+    const float bx = 1.0f - h.u - h.v, by = h.u, bz = h.v;
+    const vec3 object_position = (v0 * bx + v1 * by) + v2 * bz;
+    const vec3 object_normal = (n0 * bx + n1 * by) + n2 * bz;
+    const vec3 world_normal = normalize(xform_normal_rowvec(I->w2o, object_normal));
+    const vec3 world_position = xform_point(I->o2w, object_position);
+    const vec3 nrm = faceforward(world_normal, ray_dir, world_normal);
+    material_scatter(I->kind, ray_dir, world_position, nrm, P);
+}
+
+// ---- miss program: shader.rmiss:11-29 ----------------------------------------
+
+PTC_DEV int wrap_index(int i, int n)
+{
+    const int r = i % n;
+    return r < 0 ? r + n : r;
+}
+
+// bilinear, repeat addressing, no mips (src/renderer.cpp:861-878)
+PTC_DEV vec3 env_lookup(const DScene &S, float u, float v)
+{
+    if (!(u == u))
+    {
+        u = 0.0f;
+    }
+    if (!(v == v))
+    {
+        v = 0.0f;
+    }
+    const float x = u * (float)S.env_w - 0.5f;
+    const float y = v * (float)S.env_h - 0.5f;
+    const float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    const int x0 = wrap_index((int)x0f, (int)S.env_w);
+    const int x1 = wrap_index((int)x0f + 1, (int)S.env_w);
+    const int y0 = wrap_index((int)y0f, (int)S.env_h);
+    const int y1 = wrap_index((int)y0f + 1, (int)S.env_h);
+    const float4 t00 = S.env[(size_t)y0 * S.env_w + x0];
+    const float4 t10 = S.env[(size_t)y0 * S.env_w + x1];
+    const float4 t01 = S.env[(size_t)y1 * S.env_w + x0];
+    const float4 t11 = S.env[(size_t)y1 * S.env_w + x1];
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    vec3 c;
+    c.x = (t00.x * gx + t10.x * fx) * gy + (t01.x * gx + t11.x * fx) * fy;
+    c.y = (t00.y * gx + t10.y * fx) * gy + (t01.y * gx + t11.y * fx) * fy;
+    c.z = (t00.z * gx + t10.z * fx) * gy + (t01.z * gx + t11.z * fx) * fy;
+    return c;
+}
+
+PTC_DEV vec3 miss_color(const DScene &S, vec3 d)
+{
+    if (S.env == nullptr)
+    {
+        // the two-tone sky kept under "#if 0", shader.rmiss:13-18
+        return d.y >= 0.0f ? v3(0.75f, 0.75f, 0.75f) : v3(0.1f, 0.1f, 0.1f);
+    }
+    const float azimuth = atan2_(d.z, d.x);
+    const float inclination = acos_(d.y);
+    const float u = (azimuth + kPi) / kTwoPi;
+    const float v = inclination / kPi;
+    return env_lookup(S, u, v);
+}
+
+// ---- tone map + UNORM8: shader.rgen:141-162, :218-223 ------------------------
+
+PTC_DEV vec3 tonemap_pbr_neutral(vec3 color)
+{
+    const float start_compression = 0.8f - 0.04f;
+    const float desaturation = 0.15f;
+    const float x = fmin_(color.x, fmin_(color.y, color.z));
+    const float offset = x < 0.08f ? x - 6.25f * x * x : 0.04f;
+    color = v3(color.x - offset, color.y - offset, color.z - offset);
+    const float peak = fmax_(color.x, fmax_(color.y, color.z));
+    if (peak < start_compression)
+    {
+        return color;
+    }
+    const float d = 1.0f - start_compression;
+    const float new_peak = 1.0f - d * d / (peak + d - start_compression);
+    color = color * (new_peak / peak);
+    const float g = 1.0f - 1.0f / (desaturation * (peak - new_peak) + 1.0f);
+    const float one_minus_g = 1.0f - g;
+    return v3(color.x * one_minus_g + new_peak * g, color.y * one_minus_g + new_peak * g,
+              color.z * one_minus_g + new_peak * g);
+}
+
+// float -> UNORM8 (render target is R8G8B8A8_UNORM, src/renderer.cpp:1759-1760):
+// clamp to [0,1] (NaN -> 0), scale by 255, round to nearest even
+PTC_DEV uint32_t unorm8(float x)
+{
+    if (!(x > 0.0f))
+    {
+        return 0u;
+    }
+    if (x > 1.0f)
+    {
+        x = 1.0f;
+    }
+    return (uint32_t)__builtin_rintf(x * 255.0f);
+}
+
+PTC_DEV uint32_t pack_rgba8(vec3 lin)
+{
+    const vec3 rc = tonemap_pbr_neutral(lin);
+    return unorm8(rc.x) | (unorm8(rc.y) << 8) | (unorm8(rc.z) << 16) | 0xff000000u;
+}
+
+// ---- wide-BVH traversal + Moller-Trumbore ------------------------------------
+//
+// Node (80 bytes = 5 x uint4):
+//   w0: origin.x, origin.y, origin.z (float bits), exp_x | exp_y<<8 | exp_z<<16 | imask<<24
+//   w1: child_base, tri_base, meta[0..3], meta[4..7]
+//   w2: qlo_x[0..3], qlo_x[4..7], qlo_y[0..3], qlo_y[4..7]
+//   w3: qlo_z[0..3], qlo_z[4..7], qhi_x[0..3], qhi_x[4..7]
+//   w4: qhi_y[0..3], qhi_y[4..7], qhi_z[0..3], qhi_z[4..7]
+// Triangle (48 bytes = 3 x float4): (v0, instance), (e1, primitive), (e2, flat).
+//
+// Closest hit = lexicographic minimum over (t, flat) of all triangles passing
+// the Moller-Trumbore test below with 0 < t < tmax. Box tests only decide
+// which triangles get tested; they carry a slack that covers the rounding of
+// both the slab arithmetic and the triangle test, so no accepted triangle is
+// ever culled.
+
+constexpr float kDirEps = 8.673617379884035e-19f; // 2^-60
+constexpr int kLdsStack = 12;                      // entries per lane kept in LDS
+constexpr int kSpillStack = 52;                    // further entries in scratch
+
+PTC_DEV float clamp_dir(float d)
+{
+    return __builtin_fabsf(d) < kDirEps ? __builtin_copysignf(kDirEps, d) : d;
+}
+
+struct TraceCounters
+{
+    uint32_t nodes;
+    uint32_t tris;
+};
+
+PTC_DEV float ubyte_f(uint32_t w, int i)
+{
+    return (float)((w >> (8 * i)) & 0xffu);
+}
+
+// Moller-Trumbore on (v0, e1, e2); accepts iff det != 0, u >= 0, v >= 0,
+// u + v <= 1, 0 < t < tmax. The operation order is part of the hit definition.
+PTC_DEV bool mt_test(vec3 o, vec3 d, vec3 v0, vec3 e1, vec3 e2, float tmax, float &t,
+                     float &u, float &v)
+{
+    const vec3 p = cross(d, e2);
+    const float det = dot(e1, p);
+    if (det == 0.0f)
+    {
+        return false;
+    }
+    const float inv = 1.0f / det;
+    const vec3 tv = o - v0;
+    const float uu = dot(tv, p) * inv;
+    const vec3 q = cross(tv, e1);
+    const float vv = dot(d, q) * inv;
+    const float tt = dot(e2, q) * inv;
+    if (uu >= 0.0f && vv >= 0.0f && (uu + vv) <= 1.0f && tt > 0.0f && tt < tmax)
+    {
+        t = tt;
+        u = uu;
+        v = vv;
+        return true;
+    }
+    return false;
+}
+
+// lds_stack: this lane's column of a [kLdsStack][blockDim.x] uint2 array, i.e.
+// entry e lives at lds_stack[e * stride].
+template <bool kCount>
+PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_stack,
+                          uint32_t stride, TraceCounters *ctr)
+{
+    Hit best;
+    best.t = tmax;
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.flat = kNoHit;
+    best.instance = 0u;
+    best.primitive = 0u;
+    if (S.n_tris == 0u)
+    {
+        return best;
+    }
+    const float dcx = clamp_dir(d.x), dcy = clamp_dir(d.y), dcz = clamp_dir(d.z);
+    const float idx = 1.0f / dcx, idy = 1.0f / dcy, idz = 1.0f / dcz;
+    const bool negx = (__float_as_uint(dcx) >> 31) != 0u;
+    const bool negy = (__float_as_uint(dcy) >> 31) != 0u;
+    const bool negz = (__float_as_uint(dcz) >> 31) != 0u;
+    const uint32_t oct = (negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u);
+    const uint32_t octinv = 7u - oct;
+
+    uint2 spill[kSpillStack];
+    int sp = 0;
+    uint32_t node_idx = 0u;
+    for (;;)
+    {
+        const uint4 *__restrict__ N = S.nodes + 5u * (size_t)node_idx;
+        const uint4 w0 = N[0], w1 = N[1], w2 = N[2], w3 = N[3], w4 = N[4];
+        if (kCount)
+        {
+            ctr->nodes++;
+        }
+        const uint32_t imask = w0.w >> 24;
+        const float sx = __uint_as_float((w0.w & 0xffu) << 23) * idx;
+        const float sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * idy;
+        const float sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * idz;
+        const float bx = (__uint_as_float(w0.x) - o.x) * idx;
+        const float by = (__uint_as_float(w0.y) - o.y) * idy;
+        const float bz = (__uint_as_float(w0.z) - o.z) * idz;
+        float mag = fmax_(0.0f, __builtin_fmaf(255.0f, __builtin_fabsf(sx), __builtin_fabsf(bx)));
+        mag = fmax_(mag, __builtin_fmaf(255.0f, __builtin_fabsf(sy), __builtin_fabsf(by)));
+        mag = fmax_(mag, __builtin_fmaf(255.0f, __builtin_fabsf(sz), __builtin_fabsf(bz)));
+        const float slack = mag * (1.0f / 131072.0f);
+        // near / far plane bytes per axis, chosen by the ray's direction sign
+        const uint32_t nx0 = negx ? w3.z : w2.x, nx1 = negx ? w3.w : w2.y;
+        const uint32_t fx0 = negx ? w2.x : w3.z, fx1 = negx ? w2.y : w3.w;
+        const uint32_t ny0 = negy ? w4.x : w2.z, ny1 = negy ? w4.y : w2.w;
+        const uint32_t fy0 = negy ? w2.z : w4.x, fy1 = negy ? w2.w : w4.y;
+        const uint32_t nz0 = negz ? w4.z : w3.x, nz1 = negz ? w4.w : w3.y;
+        const uint32_t fz0 = negz ? w3.x : w4.z, fz1 = negz ? w3.y : w4.w;
+        uint32_t hitmask = 0u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+        {
+            const uint32_t meta = ((c < 4 ? w1.z : w1.w) >> (8 * (c & 3))) & 0xffu;
+            const float qnx = ubyte_f(c < 4 ? nx0 : nx1, c & 3);
+            const float qny = ubyte_f(c < 4 ? ny0 : ny1, c & 3);
+            const float qnz = ubyte_f(c < 4 ? nz0 : nz1, c & 3);
+            const float qfx = ubyte_f(c < 4 ? fx0 : fx1, c & 3);
+            const float qfy = ubyte_f(c < 4 ? fy0 : fy1, c & 3);
+            const float qfz = ubyte_f(c < 4 ? fz0 : fz1, c & 3);
+            float tn = fmax_(0.0f, __builtin_fmaf(qnx, sx, bx));
+            tn = fmax_(tn, __builtin_fmaf(qny, sy, by));
+            tn = fmax_(tn, __builtin_fmaf(qnz, sz, bz));
+            float tf = fmin_(best.t, __builtin_fmaf(qfx, sx, bx));
+            tf = fmin_(tf, __builtin_fmaf(qfy, sy, by));
+            tf = fmin_(tf, __builtin_fmaf(qfz, sz, bz));
+            if (meta != 0u && tn <= tf + slack)
+            {
+                if ((imask >> c) & 1u)
+                {
+                    hitmask |= 1u << (24u + ((uint32_t)c ^ octinv));
+                }
+                else
+                {
+                    hitmask |= (meta >> 5) << (meta & 31u);
+                }
+            }
+        }
+        uint2 ng;
+        ng.x = w1.x;
+        ng.y = (hitmask & 0xff000000u) | imask;
+        uint32_t tbits = hitmask & 0x00ffffffu;
+        const uint32_t tri_base = w1.y;
+        while (tbits)
+        {
+            const uint32_t i = (uint32_t)__builtin_ctz(tbits);
+            tbits &= tbits - 1u;
+            const float4 *__restrict__ T = S.tris + 3u * (size_t)(tri_base + i);
+            const float4 a = T[0], b = T[1], c = T[2];
+            if (kCount)
+            {
+                ctr->tris++;
+            }
+            float t, u, v;
+            if (mt_test(o, d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), tmax, t,
+                        u, v))
+            {
+                const uint32_t flat = __float_as_uint(c.w);
+                if (t < best.t || (t == best.t && flat < best.flat))
+                {
+                    best.t = t;
+                    best.u = u;
+                    best.v = v;
+                    best.flat = flat;
+                    best.instance = __float_as_uint(a.w);
+                    best.primitive = __float_as_uint(b.w);
+                }
+            }
+        }
+        if (!(ng.y & 0xff000000u))
+        {
+            if (sp == 0)
+            {
+                break;
+            }
+            --sp;
+            ng = sp < kLdsStack ? lds_stack[sp * stride] : spill[sp - kLdsStack];
+        }
+        const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng.y);
+        ng.y &= ~(1u << bit);
+        const uint32_t slot = (bit - 24u) ^ octinv;
+        if (ng.y & 0xff000000u)
+        {
+            if (sp < kLdsStack)
+            {
+                lds_stack[sp * stride] = ng;
+            }
+            else if (sp < kLdsStack + kSpillStack)
+            {
+                spill[sp - kLdsStack] = ng;
+            }
+            ++sp;
+        }
+        node_idx = ng.x + (uint32_t)__builtin_popcount(ng.y & 0xffu & ((1u << slot) - 1u));
+    }
+    return best;
+}
+
+// ---- path loop: shader.rgen:60-100 -------------------------------------------
+
+template <bool kCount>
+PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, Payload &P, uint2 *lds_stack,
+                      uint32_t stride, uint32_t &rays, TraceCounters *ctr)
+{
+    vec3 accumulated_color = v3(0.0f, 0.0f, 0.0f);
+    vec3 accumulated_reflectance = v3(1.0f, 1.0f, 1.0f);
+    for (uint32_t bounces = 0; bounces < f.max_depth; ++bounces)
+    {
+        P.attenuation = 1.0f;
+        const vec3 ray_dir = P.dir;
+        const Hit h = trace_closest<kCount>(S, P.origin, ray_dir, f.tmax, lds_stack, stride, ctr);
+        ++rays;
+        if (h.flat == kNoHit)
+        {
+            const vec3 c = miss_color(S, ray_dir);
+            P.color = c;
+            P.emissivity = c;
+            P.hit_sky = true;
+        }
+        else
+        {
+            closest_hit(S, P, ray_dir, h);
+        }
+        accumulated_color = accumulated_color + accumulated_reflectance * P.emissivity;
+        if (P.hit_sky)
+        {
+            return accumulated_color;
+        }
+        vec3 hit_color = P.color;
+        const float p = fmax_(hit_color.x, fmax_(hit_color.y, hit_color.z));
+        if (random_(P.rng) < p)
+        {
+            hit_color = hit_color / p;
+        }
+        else
+        {
+            return accumulated_color;
+        }
+        accumulated_reflectance = accumulated_reflectance * (hit_color * P.attenuation);
+    }
+    return accumulated_color;
+}
+
+// running mean of shader.rgen:202-216 (or the plain sum used when samples are
+// sharded over devices)
+PTC_DEV float4 accumulate(float4 old, float4 acc, uint32_t sample_count, uint32_t spf,
+                          bool sum_mode)
+{
+    float4 r;
+    if (sum_mode)
+    {
+        if (sample_count > 0u)
+        {
+            r = make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w);
+        }
+        else
+        {
+            r = acc;
+        }
+    }
+    else if (sample_count > 0u)
+    {
+        const float sc = (float)sample_count;
+        const float tot = (float)(sample_count + spf);
+        r = make_float4((old.x * sc + acc.x) / tot, (old.y * sc + acc.y) / tot,
+                        (old.z * sc + acc.z) / tot, (old.w * sc + acc.w) / tot);
+    }
+    else
+    {
+        const float n = (float)spf;
+        r = make_float4(acc.x / n, acc.y / n, acc.z / n, acc.w / n);
+    }
+    return r;
+}
+
+} // namespace ptc

@@ -1,0 +1,98 @@
+// Host-side objects behind the opaque handles of include/ptc.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ptc.h"
+#include "ptc_device.h"
+
+namespace ptc
+{
+
+void set_error(const std::string &msg);
+
+#define PTC_HIP_CHECK(expr)                                                              \
+    do                                                                                   \
+    {                                                                                    \
+        const hipError_t err_ = (expr);                                                  \
+        if (err_ != hipSuccess)                                                          \
+        {                                                                                \
+            ::ptc::set_error(std::string(#expr) + ": " + hipGetErrorString(err_));       \
+            return PTC_E_DEVICE;                                                         \
+        }                                                                                \
+    } while (0)
+
+struct DeviceStats
+{
+    unsigned long long rays;
+    unsigned long long paths;
+    unsigned long long nodes;
+    unsigned long long tris;
+};
+
+} // namespace ptc
+
+struct ptc_context
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    ptc::DeviceStats *d_stats = nullptr; // device counters
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    double last_render_ms = 0.0;
+    int n_cus = 256;
+    // wavefront integrator workspace, grown on demand
+    void *wf_buf = nullptr;
+    size_t wf_bytes = 0;
+};
+
+struct ptc_scene
+{
+    ptc_context *ctx = nullptr;
+    ptc::DScene d{};          // device pointers, passed to kernels by value
+    void *d_nodes = nullptr;  // n_nodes * 80 bytes
+    void *d_tris = nullptr;   // n_tris * 48 bytes
+    float *d_positions = nullptr;
+    float *d_normals = nullptr;
+    uint32_t *d_indices = nullptr;
+    ptc::DInstance *d_instances = nullptr;
+    float4 *d_env = nullptr;
+    ptc_scene_info info{};
+};
+
+struct ptc_film
+{
+    ptc_context *ctx = nullptr;
+    uint32_t width = 0, height = 0;
+    float4 *d_accum = nullptr;
+    uint32_t *d_rgba8 = nullptr;
+    bool own_accum = false, own_rgba8 = false;
+    uint32_t sample_count = 0;
+};
+
+namespace ptc
+{
+
+// BVH build on the device (ptc_bvh_build.hip). Fills scene->d_nodes, d_tris,
+// d.nodes, d.tris and the BVH fields of scene->info.
+int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &instances,
+              uint32_t n_flat_tris, uint32_t search_radius);
+
+// Render kernels (ptc_render.hip, ptc_wavefront.hip).
+int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &frame,
+                       bool count);
+int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
+                            const DFrame &frame);
+int launch_primary_hits(ptc_context *ctx, const ptc_scene *scene, const DFrame &frame,
+                        uint32_t *d_ids);
+int launch_trace(ptc_context *ctx, const ptc_scene *scene, const float *d_rays, size_t n,
+                 float tmax, ptc_hit *d_hits, bool count);
+int launch_resolve(ptc_context *ctx, ptc_film *film, int sum_mode);
+int launch_math_eval(ptc_context *ctx, int fn, const float *d_a, const float *d_b, float *d_out,
+                     float *d_out2, size_t n);
+
+} // namespace ptc

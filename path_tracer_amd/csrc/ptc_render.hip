@@ -1,0 +1,259 @@
+// Render kernels: the ray-generation program of the reference
+// (src/shaders/shader.rgen:165-224) with traversal, material and miss programs
+// inlined (megakernel), plus the stand-alone closest-hit query kernels.
+#include "ptc_internal.h"
+
+namespace ptc
+{
+namespace
+{
+
+constexpr int kBlock = 256;
+
+PTC_DEV unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        v += __shfl_xor(v, off, 64);
+    }
+    return v;
+}
+
+// One lane owns one pixel and walks all of its samples for all dispatches of
+// this call. A wave covers an 8x8 pixel tile, a block a 16x16 tile.
+template <bool kCount>
+__global__ void __launch_bounds__(kBlock)
+k_render_mega(DScene S, DFrame F, float4 *__restrict__ accum, uint32_t *__restrict__ rgba8,
+              DeviceStats *__restrict__ stats)
+{
+    __shared__ uint2 s_stack[kLdsStack * kBlock];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tiles_x = (F.width + 15u) >> 4;
+    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    uint32_t rays = 0, paths = 0;
+    TraceCounters ctr;
+    ctr.nodes = 0;
+    ctr.tris = 0;
+    if (px < F.width && py < F.height)
+    {
+        const uint32_t pixel_index = py * F.width + px;
+        uint2 *stack = s_stack + threadIdx.x;
+        float4 avg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t sample_count = F.sample_count;
+        if (sample_count > 0u)
+        {
+            avg = accum[pixel_index];
+        }
+        uint32_t frame = F.global_frame_count;
+        for (uint32_t k = 0; k < F.n_frames; ++k)
+        {
+            Payload P;
+            P.rng = seed_(pixel_index, frame);
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (uint32_t s = 0; s < F.samples_per_frame; ++s)
+            {
+                camera_ray(F, px, py, P.rng, P.origin, P.dir);
+                const vec3 c = radiance<kCount>(S, F, P, stack, kBlock, rays, &ctr);
+                ++paths;
+                acc.x += c.x;
+                acc.y += c.y;
+                acc.z += c.z;
+                acc.w += 1.0f;
+            }
+            avg = accumulate(avg, acc, sample_count, F.samples_per_frame, F.accumulate_sum != 0u);
+            sample_count += F.samples_per_frame;
+            frame += F.frame_stride;
+        }
+        accum[pixel_index] = avg;
+        vec3 lin = v3(avg.x, avg.y, avg.z);
+        if (F.accumulate_sum != 0u)
+        {
+            lin = lin / avg.w;
+        }
+        rgba8[pixel_index] = pack_rgba8(lin);
+    }
+    const unsigned long long wr = wave_sum_u64(rays), wp = wave_sum_u64(paths);
+    if (lane == 0u)
+    {
+        atomicAdd(&stats->rays, wr);
+        atomicAdd(&stats->paths, wp);
+    }
+    if (kCount)
+    {
+        const unsigned long long wn = wave_sum_u64(ctr.nodes), wt = wave_sum_u64(ctr.tris);
+        if (lane == 0u)
+        {
+            atomicAdd(&stats->nodes, wn);
+            atomicAdd(&stats->tris, wt);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_primary_hits(DScene S, DFrame F, uint32_t *__restrict__ ids)
+{
+    __shared__ uint2 s_stack[kLdsStack * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= F.width * F.height)
+    {
+        return;
+    }
+    const uint32_t px = i % F.width, py = i / F.width;
+    uint32_t rng = seed_(i, F.global_frame_count);
+    vec3 o, d;
+    camera_ray(F, px, py, rng, o, d);
+    const Hit h = trace_closest<false>(S, o, d, F.tmax, s_stack + threadIdx.x, kBlock, nullptr);
+    ids[i] = h.flat;
+}
+
+template <bool kCount>
+__global__ void __launch_bounds__(kBlock)
+k_trace(DScene S, const float *__restrict__ rays, size_t n, float tmax, ptc_hit *__restrict__ hits,
+        DeviceStats *__restrict__ stats)
+{
+    __shared__ uint2 s_stack[kLdsStack * kBlock];
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    TraceCounters ctr;
+    ctr.nodes = 0;
+    ctr.tris = 0;
+    if (i < n)
+    {
+        const vec3 o = v3(rays[6 * i + 0], rays[6 * i + 1], rays[6 * i + 2]);
+        const vec3 d = v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+        const Hit h = trace_closest<kCount>(S, o, d, tmax, s_stack + threadIdx.x, kBlock, &ctr);
+        ptc_hit out;
+        out.t = h.t;
+        out.u = h.u;
+        out.v = h.v;
+        out.flat = h.flat;
+        hits[i] = out;
+    }
+    if (kCount)
+    {
+        const unsigned long long wn = wave_sum_u64(ctr.nodes), wt = wave_sum_u64(ctr.tris);
+        if ((threadIdx.x & 63u) == 0u)
+        {
+            atomicAdd(&stats->nodes, wn);
+            atomicAdd(&stats->tris, wt);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_resolve(const float4 *__restrict__ accum, uint32_t *__restrict__ rgba8, uint32_t n, int sum_mode)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    const float4 a = accum[i];
+    vec3 lin = v3(a.x, a.y, a.z);
+    if (sum_mode)
+    {
+        lin = lin / a.w;
+    }
+    rgba8[i] = pack_rgba8(lin);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_math_eval(int fn, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out,
+            float *__restrict__ out2, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    const float x = a[i], y = b[i];
+    float r = 0.0f, r2 = 0.0f;
+    switch (fn)
+    {
+    case 0: sincos_(x, r, r2); break;
+    case 1: r = log_(x); break;
+    case 2: r = acos_(x); break;
+    case 3: r = atan2_(x, y); break;
+    case 4: r = x / y; break;
+    case 5: r = __builtin_sqrtf(x); break;
+    default: r = (float)__float_as_uint(x) * (1.0f / 4294967296.0f); break;
+    }
+    out[i] = r;
+    out2[i] = r2;
+}
+
+inline uint32_t blocks_for(size_t n)
+{
+    return (uint32_t)((n + kBlock - 1) / kBlock);
+}
+
+} // namespace
+
+int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &F,
+                       bool count)
+{
+    const uint32_t tiles = ((F.width + 15u) >> 4) * ((F.height + 15u) >> 4);
+    if (count)
+    {
+        k_render_mega<true><<<tiles, kBlock, 0, ctx->stream>>>(scene->d, F, film->d_accum, film->d_rgba8,
+                                                              ctx->d_stats);
+    }
+    else
+    {
+        k_render_mega<false><<<tiles, kBlock, 0, ctx->stream>>>(scene->d, F, film->d_accum,
+                                                               film->d_rgba8, ctx->d_stats);
+    }
+    PTC_HIP_CHECK(hipGetLastError());
+    return PTC_OK;
+}
+
+int launch_primary_hits(ptc_context *ctx, const ptc_scene *scene, const DFrame &F, uint32_t *d_ids)
+{
+    k_primary_hits<<<blocks_for((size_t)F.width * F.height), kBlock, 0, ctx->stream>>>(scene->d, F, d_ids);
+    PTC_HIP_CHECK(hipGetLastError());
+    return PTC_OK;
+}
+
+int launch_trace(ptc_context *ctx, const ptc_scene *scene, const float *d_rays, size_t n, float tmax,
+                 ptc_hit *d_hits, bool count)
+{
+    if (n == 0)
+    {
+        return PTC_OK;
+    }
+    if (count)
+    {
+        k_trace<true><<<blocks_for(n), kBlock, 0, ctx->stream>>>(scene->d, d_rays, n, tmax, d_hits,
+                                                                ctx->d_stats);
+    }
+    else
+    {
+        k_trace<false><<<blocks_for(n), kBlock, 0, ctx->stream>>>(scene->d, d_rays, n, tmax, d_hits,
+                                                                 ctx->d_stats);
+    }
+    PTC_HIP_CHECK(hipGetLastError());
+    return PTC_OK;
+}
+
+int launch_resolve(ptc_context *ctx, ptc_film *film, int sum_mode)
+{
+    const uint32_t n = film->width * film->height;
+    k_resolve<<<blocks_for(n), kBlock, 0, ctx->stream>>>(film->d_accum, film->d_rgba8, n, sum_mode);
+    PTC_HIP_CHECK(hipGetLastError());
+    return PTC_OK;
+}
+
+int launch_math_eval(ptc_context *ctx, int fn, const float *d_a, const float *d_b, float *d_out,
+                     float *d_out2, size_t n)
+{
+    if (n == 0)
+    {
+        return PTC_OK;
+    }
+    k_math_eval<<<blocks_for(n), kBlock, 0, ctx->stream>>>(fn, d_a, d_b, d_out, d_out2, n);
+    PTC_HIP_CHECK(hipGetLastError());
+    return PTC_OK;
+}
+
+} // namespace ptc

@@ -1,0 +1,139 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar: bit-exact. Hit ids, (t, u, v), the RGBA32F accumulator and the RGBA8
+target must all be identical to the oracle's, because both sides evaluate the
+same sequence of IEEE-754 binary32 operations."""
+import numpy as np
+import pytest
+
+from path_tracer_amd import renderer as R
+from path_tracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_device_math_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(0)
+    u = rng.random(200000, dtype=np.float32)
+    theta = (np.float32(6.2831855) * u).astype(np.float32)
+    s, c = ctx.math_eval(0, theta)
+    so, co = oracle.math_eval(0, oracle.MATH_PORTABLE, theta)
+    assert np.array_equal(_bits(s), _bits(so)) and np.array_equal(_bits(c), _bits(co))
+    x = np.maximum(u, np.float32(1.175494351e-38))
+    assert np.array_equal(_bits(ctx.math_eval(1, x)), _bits(oracle.math_eval(1, oracle.MATH_PORTABLE, x)))
+    y = (2 * u - 1).astype(np.float32)
+    assert np.array_equal(_bits(ctx.math_eval(2, y)), _bits(oracle.math_eval(2, oracle.MATH_PORTABLE, y)))
+    z = rng.standard_normal(200000).astype(np.float32)
+    w = rng.standard_normal(200000).astype(np.float32)
+    assert np.array_equal(_bits(ctx.math_eval(3, z, w)),
+                          _bits(oracle.math_eval(3, oracle.MATH_PORTABLE, z, w)))
+    # IEEE division, square root and uint -> float conversion
+    big = (z * np.float32(1e-3)).astype(np.float32)
+    assert np.array_equal(_bits(ctx.math_eval(4, z, w)), _bits(z / w))
+    assert np.array_equal(_bits(ctx.math_eval(4, big, w)), _bits(big / w))
+    assert np.array_equal(_bits(ctx.math_eval(5, np.abs(z))), _bits(np.sqrt(np.abs(z))))
+    ints = rng.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32)
+    ref = (ints.astype(np.float32) * np.float32(1.0 / 4294967296.0)).astype(np.float32)
+    assert np.array_equal(_bits(ctx.math_eval(6, ints.view(np.float32))), _bits(ref))
+    # subnormals are kept, not flushed
+    tiny = np.full(16, 1e-40, np.float32)
+    assert np.array_equal(_bits(ctx.math_eval(4, tiny, np.full(16, 2.0, np.float32))), _bits(tiny / np.float32(2)))
+
+
+def _small_knot():
+    return scenes.knot_mesh(nu=96, nv=24)
+
+
+SCENES = {
+    "cornell": lambda: scenes.cornell_box(),
+    "cornell_glass_mirror": lambda: scenes.cornell_box(tall_kind=1, short_kind=3),
+    "ref4_knot_sky": lambda: scenes.ref4_scene(_small_knot(), scenes.procedural_sky(64, 32)),
+    "knot_specular_sky": lambda: scenes.dragon_scene(envmap=scenes.procedural_sky(64, 32), nu=160, nv=40),
+}
+
+
+@pytest.fixture(scope="module", params=sorted(SCENES))
+def scene_pair(request, ctx, oracle):
+    sc = SCENES[request.param]()
+    dev = R.DeviceScene(ctx, sc)
+    orc = oracle.Scene(*sc.oracle_args())
+    yield request.param, sc, dev, orc
+    dev.close()
+
+
+def test_bvh_structure_and_triangles(scene_pair, oracle):
+    name, sc, dev, orc = scene_pair
+    nodes, tris = dev.read_bvh()
+    assert dev.info.n_triangles == orc.n_triangles == sc.n_triangles
+    rc, cost = oracle.bvh8_validate(nodes, tris, orc.world_triangles())
+    assert rc == 0, f"{name}: BVH validation code {rc}"
+    assert abs(cost - dev.info.sah_cost) <= 0.02 * cost + 1e-3
+
+
+def test_trace_matches_brute_force(scene_pair, oracle):
+    name, sc, dev, orc = scene_pair
+    rays = np.concatenate([scenes.random_rays(30000, seed=3), scenes.random_rays(10000, seed=4, radius=0.3)])
+    hits, st = dev.trace(rays, count=True)
+    use_bvh = orc.n_triangles > 2000  # brute force is the definition; BVH only to keep the test short
+    ref, _ = orc.intersect(rays, use_bvh=use_bvh)
+    assert np.array_equal(hits["flat"], ref["id"]), f"{name}: hit ids differ"
+    hit = ref["id"] != oracle.NO_HIT
+    for k in ("t", "u", "v"):
+        assert np.array_equal(_bits(hits[k][hit]), _bits(ref[k][hit])), f"{name}: {k} bits differ"
+    # the oracle walking the device-built tree visits exactly the same nodes
+    nodes, tris = dev.read_bvh()
+    ref8, st8 = oracle.bvh8_intersect(nodes, tris, rays)
+    assert np.array_equal(ref8["id"], ref["id"])
+    assert st.nodes_visited == st8.nodes_visited and st.tris_tested == st8.tris_tested
+
+
+def test_primary_hit_ids(scene_pair, oracle):
+    name, sc, dev, orc = scene_pair
+    w, h = 96, 64
+    cam = R.default_camera(w, h)
+    for frame in (0, 17):
+        ids = dev.primary_hits(cam, w, h, frame)
+        ref = orc.primary_hits(oracle.make_push(cam.as_dict(), frame=frame), w, h,
+                               use_bvh=orc.n_triangles > 2000)
+        assert np.array_equal(ids, ref), f"{name}: {np.count_nonzero(ids != ref)} primary ids differ"
+
+
+@pytest.mark.parametrize("spf,n_frames", [(1, 3), (2, 2)])
+def test_render_bit_exact(scene_pair, ctx, oracle, spf, n_frames):
+    name, sc, dev, orc = scene_pair
+    w, h = 80, 48
+    cam = R.default_camera(w, h)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.max_depth = 8
+    # two calls: a fresh film, then a continuation with sample_count > 0
+    rr.render(cam, frame=5, samples_per_frame=spf, n_frames=n_frames)
+    rr.render(cam, frame=5 + n_frames, samples_per_frame=spf, n_frames=1)
+    acc, img = rr.read_accum(), rr.read_rgba8()
+    push = oracle.make_push(cam.as_dict(), frame=5, sample_count=0, samples_per_frame=spf)
+    ref_acc, ref_img, st = orc.render(push, w, h, n_frames=n_frames + 1, max_depth=8,
+                                      use_bvh=orc.n_triangles > 2000)
+    assert rr.sample_count == spf * (n_frames + 1)
+    assert np.array_equal(_bits(acc), _bits(ref_acc)), \
+        f"{name}: {np.count_nonzero(_bits(acc) != _bits(ref_acc))} accumulator words differ"
+    assert np.array_equal(img, ref_img)
+    rr.close()
+
+
+def test_ray_and_path_counters(ctx, oracle):
+    sc = scenes.cornell_box()
+    dev = R.DeviceScene(ctx, sc)
+    orc = oracle.Scene(*sc.oracle_args())
+    w, h = 64, 64
+    cam = R.default_camera(w, h)
+    rr = R.RenderResources(ctx, w, h, dev)
+    ctx.reset_stats()
+    rr.render(cam, frame=0, n_frames=2)
+    st = ctx.stats()
+    _, _, ref = orc.render(oracle.make_push(cam.as_dict()), w, h, n_frames=2, use_bvh=False)
+    assert (st.rays, st.paths) == (ref.rays, ref.paths)
+    rr.close()
+    dev.close()
