@@ -167,7 +167,8 @@ typedef struct ptc_render_params
     float tmax;                  /* the literal 10000.0 of shader.rgen:77 (0 -> 10000) */
     uint32_t integrator;         /* PTC_INTEGRATOR_* */
     uint32_t accumulate;         /* PTC_ACCUM_* */
-    uint32_t reserved[4];
+    uint32_t instrument;         /* 1: also count BVH nodes / triangles visited */
+    uint32_t reserved[3];
 } ptc_render_params;
 
 typedef struct ptc_stats
@@ -245,6 +246,10 @@ int ptc_trace_rays_device(ptc_context *ctx, const ptc_scene *scene,
                           void *hits_dev);
 
 int ptc_get_stats(ptc_context *ctx, ptc_stats *out);
+/* Device durations (HIP events on the context's stream) of the ptc_render
+ * calls issued since the last call of this function, oldest first, at most
+ * 256 kept. Synchronises the stream. *n_out receives the number written. */
+int ptc_render_times(ptc_context *ctx, double *ms_out, size_t capacity, size_t *n_out);
 int ptc_reset_stats(ptc_context *ctx);
 int ptc_synchronize(ptc_context *ctx);
 

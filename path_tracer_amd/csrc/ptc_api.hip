@@ -244,6 +244,11 @@ void ptc_context_destroy(ptc_context *ctx)
     (void)hipFree(ctx->wf_buf);
     (void)hipEventDestroy(ctx->ev_start);
     (void)hipEventDestroy(ctx->ev_stop);
+    for (auto &p : ctx->ev_pool)
+    {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
     if (ctx->own_stream)
     {
         (void)hipStreamDestroy(ctx->stream);
@@ -696,7 +701,19 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
     F.max_depth = params->max_depth ? params->max_depth : 32u;
     F.tmax = params->tmax > 0.0f ? params->tmax : 10000.0f;
     F.accumulate_sum = params->accumulate == PTC_ACCUM_SUM ? 1u : 0u;
-    PTC_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
+    // one event pair per call, kept until ptc_render_times() collects them
+    constexpr size_t kMaxTimed = 256;
+    if (ctx->ev_used == ctx->ev_pool.size() && ctx->ev_pool.size() < kMaxTimed)
+    {
+        hipEvent_t a, b;
+        PTC_HIP_CHECK(hipEventCreate(&a));
+        PTC_HIP_CHECK(hipEventCreate(&b));
+        ctx->ev_pool.emplace_back(a, b);
+    }
+    const bool timed = ctx->ev_used < ctx->ev_pool.size();
+    hipEvent_t ev0 = timed ? ctx->ev_pool[ctx->ev_used].first : ctx->ev_start;
+    hipEvent_t ev1 = timed ? ctx->ev_pool[ctx->ev_used].second : ctx->ev_stop;
+    PTC_HIP_CHECK(hipEventRecord(ev0, ctx->stream));
     int rc;
     if (params->integrator == PTC_INTEGRATOR_WAVEFRONT)
     {
@@ -704,13 +721,17 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
     }
     else
     {
-        rc = launch_render_mega(ctx, scene, film, F, false);
+        rc = launch_render_mega(ctx, scene, film, F, params->instrument != 0);
     }
     if (rc != PTC_OK)
     {
         return rc;
     }
-    PTC_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
+    PTC_HIP_CHECK(hipEventRecord(ev1, ctx->stream));
+    if (timed)
+    {
+        ++ctx->ev_used;
+    }
     film->sample_count += (uint32_t)added;
     return PTC_OK;
 }
@@ -853,16 +874,48 @@ int ptc_get_stats(ptc_context *ctx, ptc_stats *out)
     DeviceStats s{};
     PTC_HIP_CHECK(hipMemcpyAsync(&s, ctx->d_stats, sizeof s, hipMemcpyDeviceToHost, ctx->stream));
     PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop) == hipSuccess)
+    if (ctx->ev_used > 0)
     {
-        ctx->last_render_ms = ms;
+        float ms = 0.0f;
+        const auto &p = ctx->ev_pool[ctx->ev_used - 1];
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess)
+        {
+            ctx->last_render_ms = ms;
+        }
     }
     out->rays = s.rays;
     out->paths = s.paths;
     out->nodes_visited = s.nodes;
     out->tris_tested = s.tris;
     out->render_ms = ctx->last_render_ms;
+    return PTC_OK;
+}
+
+int ptc_render_times(ptc_context *ctx, double *ms_out, size_t capacity, size_t *n_out)
+{
+    if (!ctx || !n_out || (capacity && !ms_out))
+    {
+        set_error("ptc_render_times: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    size_t n = 0;
+    for (size_t i = 0; i < ctx->ev_used && n < capacity; ++i)
+    {
+        float ms = 0.0f;
+        PTC_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        ms_out[n++] = ms;
+    }
+    if (ctx->ev_used > 0)
+    {
+        ctx->last_render_ms = n ? ms_out[n - 1] : ctx->last_render_ms;
+    }
+    ctx->ev_used = 0;
+    *n_out = n;
     return PTC_OK;
 }
 

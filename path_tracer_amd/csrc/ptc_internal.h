@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/ptc.h"
@@ -42,8 +43,10 @@ struct ptc_context
     hipStream_t stream = nullptr;
     bool own_stream = false;
     ptc::DeviceStats *d_stats = nullptr; // device counters
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr; // most recent ptc_render
     double last_render_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; // one pair per recorded render
+    size_t ev_used = 0;
     int n_cus = 256;
     // wavefront integrator workspace, grown on demand
     void *wf_buf = nullptr;

@@ -95,7 +95,7 @@ class RenderParams(C.Structure):
                 ("n_frames", C.c_uint32), ("frame_stride", C.c_uint32),
                 ("max_depth", C.c_uint32), ("tmax", C.c_float),
                 ("integrator", C.c_uint32), ("accumulate", C.c_uint32),
-                ("reserved", C.c_uint32 * 4)]
+                ("instrument", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class Stats(C.Structure):
@@ -112,7 +112,8 @@ EXPORTS = [
     "ptc_film_create", "ptc_film_destroy", "ptc_film_reset", "ptc_film_sample_count",
     "ptc_film_set_sample_count", "ptc_film_read_accum", "ptc_film_read_rgba8",
     "ptc_film_accum_device_ptr", "ptc_film_resolve", "ptc_render", "ptc_primary_hits",
-    "ptc_trace_rays", "ptc_trace_rays_device", "ptc_get_stats", "ptc_reset_stats",
+    "ptc_trace_rays", "ptc_trace_rays_device", "ptc_get_stats", "ptc_render_times",
+    "ptc_reset_stats",
     "ptc_synchronize", "ptc_write_png", "ptc_math_eval",
 ]
 
@@ -154,6 +155,7 @@ def lib():
         L.ptc_trace_rays.argtypes = [vp, vp, vp, sz, f32, vp, C.POINTER(Stats)]
         L.ptc_trace_rays_device.argtypes = [vp, vp, vp, sz, f32, vp]
         L.ptc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.ptc_render_times.argtypes = [vp, vp, sz, C.POINTER(sz)]
         L.ptc_reset_stats.argtypes = [vp]
         L.ptc_synchronize.argtypes = [vp]
         L.ptc_write_png.argtypes = [vp, C.c_char_p]
@@ -285,6 +287,7 @@ class RenderContext:
         self.handle = h
         self.device = device
         self.global_frame_count = 0  # Vulkan_context::global_frame_count
+        self._children = []  # weak references to scenes / films created on this context
 
     def set_stream(self, hip_stream: int):
         _check(lib().ptc_context_set_stream(self.handle, C.c_void_p(hip_stream)))
@@ -300,6 +303,13 @@ class RenderContext:
     def reset_stats(self):
         _check(lib().ptc_reset_stats(self.handle))
 
+    def render_times(self) -> np.ndarray:
+        """Device milliseconds of every ptc_render since the last call."""
+        out = np.empty(256, np.float64)
+        n = C.c_size_t(0)
+        _check(lib().ptc_render_times(self.handle, out.ctypes.data, out.size, C.byref(n)))
+        return out[: n.value].copy()
+
     def math_eval(self, fn: int, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float32)
         b = np.ascontiguousarray(b, dtype=np.float32) if b is not None else np.ones_like(a)
@@ -308,8 +318,18 @@ class RenderContext:
                                    out.ctypes.data, out2.ctypes.data, a.size))
         return (out, out2) if fn == 0 else out
 
+    def _adopt(self, child):
+        import weakref
+        self._children.append(weakref.ref(child))
+
     def close(self):
+        """Destroys the context after every scene and film created on it."""
         if self.handle:
+            for ref in reversed(self._children):
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             lib().ptc_context_destroy(self.handle)
             self.handle = None
 
@@ -356,6 +376,7 @@ class DeviceScene:
                                       len(scene.instances), C.byref(env) if env else None,
                                       C.byref(opts), C.byref(h)))
         self.handle = h
+        ctx._adopt(self)
         self.info = SceneInfo()
         _check(lib().ptc_scene_get_info(h, C.byref(self.info)))
 
@@ -407,6 +428,7 @@ class RenderResources:
         _check(lib().ptc_film_create(ctx.handle, width, height, C.c_void_p(accum_dev or None),
                                      C.c_void_p(rgba8_dev or None), C.byref(h)))
         self.film = h
+        ctx._adopt(self)
         # src/renderer.cpp:1950-1952
         self.samples_to_render = 1000
         self.samples_per_frame = 1
@@ -415,6 +437,7 @@ class RenderResources:
         self.tmax = 10000.0
         self.integrator = INTEGRATOR_MEGAKERNEL
         self.accumulate = ACCUM_RUNNING_MEAN
+        self.instrument = False
 
     @property
     def sample_count(self) -> int:
@@ -435,6 +458,7 @@ class RenderResources:
         p.tmax = self.tmax
         p.integrator = self.integrator
         p.accumulate = self.accumulate
+        p.instrument = int(self.instrument)
         _check(lib().ptc_render(self.ctx.handle, self.scene.handle, self.film, C.byref(camera),
                                 C.byref(p)))
 
