@@ -1,0 +1,55 @@
+"""The C-ABI library loads and exports every symbol include/ptc.h declares; the
+structs that cross the boundary have the sizes the header implies. No compute
+call is made here (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+from path_tracer_amd import renderer as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ptc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = C.CDLL(R.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), f"libptcore.so does not export {n}"
+    assert sorted(R.EXPORTS) == names
+
+
+def test_struct_layouts():
+    assert C.sizeof(R.Camera) == 84          # 21 floats, src/camera.hpp:6-19
+    assert C.sizeof(R.MeshDesc) == 32
+    assert C.sizeof(R.InstanceDesc) == 56
+    assert C.sizeof(R.EnvmapDesc) == 16
+    assert C.sizeof(R.BuildOptions) == 32
+    assert C.sizeof(R.SceneInfo) == 32
+    assert C.sizeof(R.RenderParams) == 48
+    assert C.sizeof(R.Stats) == 40
+    assert R.HIT_DTYPE.itemsize == 16
+
+
+def test_errors_are_reported_without_a_device_call():
+    L = R.lib()
+    assert L.ptc_render(None, None, None, None, None) == -1
+    assert b"NULL" in L.ptc_last_error()
+    assert L.ptc_film_reset(None) == -1
+    assert L.ptc_film_sample_count(None) == 0
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under path_tracer_amd/ may import, include or link oracle/."""
+    pkg = os.path.join(ROOT, "path_tracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pt_oracle" not in text and "oracle/" not in text, f"{f} references the oracle"

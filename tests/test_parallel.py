@@ -1,0 +1,64 @@
+"""spp sharding: schedule arithmetic, and a world_size-2 gloo run on the CPU in
+which each rank renders its share with the oracle (standing in for the GPU),
+the sums are reduced, and the result is compared with the single-process
+render of the same frame schedule."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from path_tracer_amd import parallel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_frame_schedule_partitions_the_single_gpu_schedule():
+    for world in (1, 2, 4, 8):
+        frames = sorted(f for r in range(world) for f in parallel.frames_of(r, world, 100, 16))
+        assert frames == list(range(100, 100 + 16 * world))
+    assert parallel.split_spp(10, 4) == [3, 3, 2, 2] and sum(parallel.split_spp(4096, 8)) == 4096
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["PT_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from oracle import pt_oracle as O
+from path_tracer_amd import parallel, renderer as R, scenes
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+sc = scenes.cornell_box()
+orc = O.Scene(*sc.oracle_args())
+w, h, spp = 24, 16, 3
+cam = R.default_camera(w, h)
+acc = None
+for k, f in enumerate(parallel.frames_of(rank, world, 7, spp)):
+    acc, _, _ = orc.render(O.make_push(cam.as_dict(), frame=f, sample_count=k), w, h, accum=acc,
+                           accumulate_sum=True, use_bvh=False, want_rgba8=False)
+t = torch.from_numpy(acc)
+parallel.reduce_sum(t, dst=0)
+if rank == 0:
+    ref, _, _ = orc.render(O.make_push(cam.as_dict(), frame=7), w, h, n_frames=spp * world,
+                           accumulate_sum=True, use_bvh=False, want_rgba8=False)
+    got = t.numpy()
+    assert (got[..., 3] == spp * world).all()
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-6), np.abs(got - ref).max()
+    mean = parallel.normalise(t).numpy()
+    assert np.allclose(mean[..., :3], ref[..., :3] / (spp * world), rtol=1e-5, atol=1e-6)
+    print("PARALLEL_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_reduce_matches_single_process(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, PT_ROOT=ROOT, OMP_NUM_THREADS="2")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "PARALLEL_OK" in out.stdout
