@@ -84,16 +84,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=16)
     ap.add_argument("--scene", default="dragon")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-depth", type=int, default=32)
-    ap.add_argument("--integrator", default="megakernel", choices=["megakernel", "wavefront"])
+    ap.add_argument("--integrator", default="wavefront", choices=["megakernel", "wavefront"])
     ap.add_argument("--env-res", type=int, default=2048)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-png", default="")
+    ap.add_argument("--wavefront-bounces", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -124,6 +125,7 @@ def main():
     rr.max_depth = args.max_depth
     rr.accumulate = R.ACCUM_SUM
     rr.integrator = R.INTEGRATOR_WAVEFRONT if args.integrator == "wavefront" else R.INTEGRATOR_MEGAKERNEL
+    rr.wavefront_bounces = args.wavefront_bounces
     info = rr.scene.info
     spp = args.spp_per_step
 

@@ -168,7 +168,13 @@ typedef struct ptc_render_params
     uint32_t integrator;         /* PTC_INTEGRATOR_* */
     uint32_t accumulate;         /* PTC_ACCUM_* */
     uint32_t instrument;         /* 1: also count BVH nodes / triangles visited */
-    uint32_t reserved[3];
+    /* Wavefront integrator: bounces after the first that run as separate
+     * traversal / shading launches over compacted queues before one persistent
+     * launch finishes the remaining paths. 0 (default, fastest measured): the
+     * persistent launch starts right after the first bounce. Does not change
+     * results. */
+    uint32_t wavefront_bounces;
+    uint32_t reserved[2];
 } ptc_render_params;
 
 typedef struct ptc_stats

@@ -947,6 +947,8 @@ static void build_bvh(pt_scene *S)
 /* --- traversal of the oracle's own BVH -------------------------------------*/
 
 #define PT_DIR_EPS 8.673617379884035e-19f /* 2^-60 */
+#define PT_SLAB_SLACK (1.0f / 262144.0f)  /* per-axis slack on slab distances */
+#define PT_TLIMIT_PAD 1.00006103515625f   /* 1 + 2^-14: pad on the culling t */
 
 static inline float clamp_dir(float d)
 {
@@ -972,16 +974,16 @@ static pt_hit intersect_bvh(const pt_scene *S, pt_vec3 o, pt_vec3 d, float tmax,
     {
         const bnode_t *N = &S->nodes[stack[--sp]];
         ++nodes;
-        float tn = 0.0f, tf = best.t, mag = 0.0f;
+        float tn = 0.0f, tf = best.t * PT_TLIMIT_PAD;
         for (int k = 0; k < 3; ++k)
         {
             const float t0 = (N->lo[k] - od[k]) * idir[k];
             const float t1 = (N->hi[k] - od[k]) * idir[k];
-            tn = pt_max(tn, pt_min(t0, t1));
-            tf = pt_min(tf, pt_max(t0, t1));
-            mag = pt_max(mag, pt_max(fabsf(t0), fabsf(t1)));
+            const float e = pt_max(fabsf(t0), fabsf(t1)) * PT_SLAB_SLACK;
+            tn = pt_max(tn, pt_min(t0, t1) - e);
+            tf = pt_min(tf, pt_max(t0, t1) + e);
         }
-        if (!(tn <= tf + mag * (1.0f / 131072.0f)))
+        if (!(tn <= tf))
         {
             continue;
         }
@@ -1102,15 +1104,17 @@ static pt_hit bvh8_trace(const node8_t *nodes, const tri8_t *tris, pt_vec3 o,
     {
         const node8_t *N = &nodes[node_idx];
         ++n_nodes;
-        float s[3], b[3], mag = 0.0f;
+        float s[3], bn[3], bf[3];
         for (int k = 0; k < 3; ++k)
         {
             const float scale = pt_u2f((uint32_t)N->exp[k] << 23);
             s[k] = scale * idir[k];
-            b[k] = (N->origin[k] - od[k]) * idir[k];
-            mag = pt_max(mag, fmaf(255.0f, fabsf(s[k]), fabsf(b[k])));
+            const float b = (N->origin[k] - od[k]) * idir[k];
+            const float e = fmaf(255.0f, fabsf(s[k]), fabsf(b)) * PT_SLAB_SLACK;
+            bn[k] = b - e;
+            bf[k] = b + e;
         }
-        const float slack = mag * (1.0f / 131072.0f);
+        const float tlim = best.t * PT_TLIMIT_PAD;
         uint32_t hitmask = 0;
         for (uint32_t c = 0; c < 8; ++c)
         {
@@ -1119,15 +1123,15 @@ static pt_hit bvh8_trace(const node8_t *nodes, const tri8_t *tris, pt_vec3 o,
             {
                 continue;
             }
-            float tn = 0.0f, tf = best.t;
+            float tn = 0.0f, tf = tlim;
             for (int k = 0; k < 3; ++k)
             {
                 const float qn = (float)(neg[k] ? N->qhi[k][c] : N->qlo[k][c]);
                 const float qf = (float)(neg[k] ? N->qlo[k][c] : N->qhi[k][c]);
-                tn = pt_max(tn, fmaf(qn, s[k], b[k]));
-                tf = pt_min(tf, fmaf(qf, s[k], b[k]));
+                tn = pt_max(tn, fmaf(qn, s[k], bn[k]));
+                tf = pt_min(tf, fmaf(qf, s[k], bf[k]));
             }
-            if (tn <= tf + slack)
+            if (tn <= tf)
             {
                 if ((N->imask >> c) & 1u)
                 {

@@ -701,6 +701,7 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
     F.max_depth = params->max_depth ? params->max_depth : 32u;
     F.tmax = params->tmax > 0.0f ? params->tmax : 10000.0f;
     F.accumulate_sum = params->accumulate == PTC_ACCUM_SUM ? 1u : 0u;
+    F.wavefront_bounces = params->wavefront_bounces;
     // one event pair per call, kept until ptc_render_times() collects them
     constexpr size_t kMaxTimed = 256;
     if (ctx->ev_used == ctx->ev_pool.size() && ctx->ev_pool.size() < kMaxTimed)

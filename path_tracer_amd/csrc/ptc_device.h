@@ -58,6 +58,7 @@ struct DFrame
     uint32_t n_frames;
     uint32_t frame_stride;
     uint32_t accumulate_sum;
+    uint32_t wavefront_bounces; // bounces run as trace / shade launch pairs before the drain launch
 };
 
 struct Hit
@@ -398,11 +399,16 @@ PTC_DEV uint32_t pack_rgba8(vec3 lin)
 //
 // Closest hit = lexicographic minimum over (t, flat) of all triangles passing
 // the Moller-Trumbore test below with 0 < t < tmax. Box tests only decide
-// which triangles get tested; they carry a slack that covers the rounding of
-// both the slab arithmetic and the triangle test, so no accepted triangle is
-// ever culled.
+// which triangles get tested. They are made conservative three ways: leaf boxes
+// are padded by 2^-18 of the scene's largest coordinate at build time; every
+// slab distance gets a per-axis slack of 2^-18 of the magnitudes it is computed
+// from; and the current best t is padded by 2^-14 before it culls. Together
+// these cover the rounding of the slab arithmetic and of the triangle test, so
+// no triangle the test would accept is ever culled.
 
 constexpr float kDirEps = 8.673617379884035e-19f; // 2^-60
+constexpr float kSlabSlack = 1.0f / 262144.0f;     // 2^-18
+constexpr float kTLimitPad = 1.00006103515625f;    // 1 + 2^-14
 constexpr int kLdsStack = 12;                      // entries per lane kept in LDS
 constexpr int kSpillStack = 52;                    // further entries in scratch
 
@@ -492,10 +498,14 @@ PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *ld
         const float bx = (__uint_as_float(w0.x) - o.x) * idx;
         const float by = (__uint_as_float(w0.y) - o.y) * idy;
         const float bz = (__uint_as_float(w0.z) - o.z) * idz;
-        float mag = fmax_(0.0f, __builtin_fmaf(255.0f, __builtin_fabsf(sx), __builtin_fabsf(bx)));
-        mag = fmax_(mag, __builtin_fmaf(255.0f, __builtin_fabsf(sy), __builtin_fabsf(by)));
-        mag = fmax_(mag, __builtin_fmaf(255.0f, __builtin_fabsf(sz), __builtin_fabsf(bz)));
-        const float slack = mag * (1.0f / 131072.0f);
+        // per-axis slack: 2^-18 of the magnitudes entering each slab distance,
+        // subtracted from entry distances and added to exit distances
+        const float ex = __builtin_fmaf(255.0f, __builtin_fabsf(sx), __builtin_fabsf(bx)) * kSlabSlack;
+        const float ey = __builtin_fmaf(255.0f, __builtin_fabsf(sy), __builtin_fabsf(by)) * kSlabSlack;
+        const float ez = __builtin_fmaf(255.0f, __builtin_fabsf(sz), __builtin_fabsf(bz)) * kSlabSlack;
+        const float bnx = bx - ex, bny = by - ey, bnz = bz - ez;
+        const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez;
+        const float tlim = best.t * kTLimitPad;
         // near / far plane bytes per axis, chosen by the ray's direction sign
         const uint32_t nx0 = negx ? w3.z : w2.x, nx1 = negx ? w3.w : w2.y;
         const uint32_t fx0 = negx ? w2.x : w3.z, fx1 = negx ? w2.y : w3.w;
@@ -514,13 +524,13 @@ PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *ld
             const float qfx = ubyte_f(c < 4 ? fx0 : fx1, c & 3);
             const float qfy = ubyte_f(c < 4 ? fy0 : fy1, c & 3);
             const float qfz = ubyte_f(c < 4 ? fz0 : fz1, c & 3);
-            float tn = fmax_(0.0f, __builtin_fmaf(qnx, sx, bx));
-            tn = fmax_(tn, __builtin_fmaf(qny, sy, by));
-            tn = fmax_(tn, __builtin_fmaf(qnz, sz, bz));
-            float tf = fmin_(best.t, __builtin_fmaf(qfx, sx, bx));
-            tf = fmin_(tf, __builtin_fmaf(qfy, sy, by));
-            tf = fmin_(tf, __builtin_fmaf(qfz, sz, bz));
-            if (meta != 0u && tn <= tf + slack)
+            float tn = fmax_(0.0f, __builtin_fmaf(qnx, sx, bnx));
+            tn = fmax_(tn, __builtin_fmaf(qny, sy, bny));
+            tn = fmax_(tn, __builtin_fmaf(qnz, sz, bnz));
+            float tf = fmin_(tlim, __builtin_fmaf(qfx, sx, bfx));
+            tf = fmin_(tf, __builtin_fmaf(qfy, sy, bfy));
+            tf = fmin_(tf, __builtin_fmaf(qfz, sz, bfz));
+            if (meta != 0u && tn <= tf)
             {
                 if ((imask >> c) & 1u)
                 {

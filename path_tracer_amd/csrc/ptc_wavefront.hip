@@ -1,11 +1,463 @@
-// Wavefront integrator (placeholder until the queue kernels land).
+// Wavefront integrator: the path loop of src/shaders/shader.rgen:60-100 turned
+// inside out. Instead of one lane walking one pixel's path to the end (lanes of
+// a wave then idle while the longest path finishes), every bounce is a pair of
+// launches over a compacted queue of live paths:
+//
+//   k_wf_primary  bounce 0, fused: camera ray -> traversal -> material / sky.
+//                 Camera rays are coherent, so fusing costs nothing and saves
+//                 writing 3/4 of the paths (those that end at the sky) to HBM.
+//   k_wf_trace    traversal + Moller-Trumbore for queue slot i -> hit record
+//   k_wf_shade    material / sky, emission, Russian roulette; survivors are
+//                 appended to the next queue with one atomic per wave
+//                 (ballot + popcount prefix), so the next launch runs full waves
+//   k_wf_resolve  folds the per-path radiances of each pixel, in dispatch
+//                 order, into the film exactly as shader.rgen:202-223 does
+//
+// A path is (pixel, dispatch k); its id is k * n_pixels + pixel. Live-path state
+// lives in two ping-pong sets of SoA arrays indexed by queue slot, so every
+// access of the per-bounce kernels is coalesced; only the final radiance is
+// scattered by path id. Each path carries its own RNG state, so results do not
+// depend on queue order and equal the megakernel's bit for bit.
 #include "ptc_internal.h"
+
+#include <algorithm>
 
 namespace ptc
 {
-int launch_render_wavefront(ptc_context *, const ptc_scene *, ptc_film *, const DFrame &)
+namespace
 {
-    set_error("wavefront integrator not built yet");
-    return PTC_E_INVALID;
+
+constexpr int kBlock = 256;
+
+struct WfState
+{
+    float4 *a; // origin.xyz, rng
+    float4 *b; // dir.xyz, path id
+    float4 *c; // throughput.xyz, radiance.x
+    float2 *d; // radiance.yz
+};
+
+struct WfBuffers
+{
+    WfState q[2];
+    float4 *hit;      // t, u, v, flat
+    uint2 *hit_ids;   // instance, primitive
+    float4 *radiance; // per path id: final radiance (w unused)
+    uint32_t *counts; // counts[b] = live paths entering bounce b
+    // RNG state a finished path hands to the next sample of the same pixel and
+    // dispatch (samples_per_frame > 1 continue one stream, shader.rgen:175-179);
+    // nullptr when samples_per_frame == 1
+    uint32_t *carry;
+    uint32_t spf;      // samples per dispatch
+    uint32_t n_pixels;
+};
+
+// path id = (dispatch * spf + sample) * n_pixels + pixel
+PTC_DEV void finish_path(const WfBuffers &B, uint32_t pid, vec3 L, uint32_t rng)
+{
+    B.radiance[pid] = make_float4(L.x, L.y, L.z, 1.0f);
+    if (B.carry != nullptr)
+    {
+        const uint32_t per_dispatch = B.spf * B.n_pixels;
+        B.carry[(pid / per_dispatch) * B.n_pixels + pid % B.n_pixels] = rng;
+    }
 }
+
+PTC_DEV uint32_t lane_id()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Appends the calling lanes for which alive is true to a queue; returns the
+// slot. One atomic per wave.
+PTC_DEV uint32_t queue_append(bool alive, uint32_t *counter)
+{
+    const unsigned long long mask = __ballot(alive);
+    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+    const uint32_t lane = lane_id();
+    uint32_t base = 0;
+    if (n != 0u)
+    {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+        if (lane == leader)
+        {
+            base = atomicAdd(counter, n);
+        }
+        base = __shfl(base, (int)leader, 64);
+    }
+    const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    return base + rank;
+}
+
+// One bounce of radiance() after the closest-hit query: shader.rgen:80-96.
+// Returns true when the path continues.
+PTC_DEV bool shade_bounce(const DScene &S, const Hit &h, Payload &P, vec3 &T, vec3 &L)
+{
+    const vec3 ray_dir = P.dir;
+    P.attenuation = 1.0f;
+    if (h.flat == kNoHit)
+    {
+        const vec3 c = miss_color(S, ray_dir);
+        P.color = c;
+        P.emissivity = c;
+        P.hit_sky = true;
+    }
+    else
+    {
+        closest_hit(S, P, ray_dir, h);
+    }
+    L = L + T * P.emissivity;
+    if (P.hit_sky)
+    {
+        return false;
+    }
+    vec3 hit_color = P.color;
+    const float p = fmax_(hit_color.x, fmax_(hit_color.y, hit_color.z));
+    if (random_(P.rng) < p)
+    {
+        hit_color = hit_color / p;
+    }
+    else
+    {
+        return false;
+    }
+    T = T * (hit_color * P.attenuation);
+    return true;
+}
+
+PTC_DEV void store_state(const WfState &q, uint32_t slot, const Payload &P, uint32_t pid, vec3 T, vec3 L)
+{
+    q.a[slot] = make_float4(P.origin.x, P.origin.y, P.origin.z, __uint_as_float(P.rng));
+    q.b[slot] = make_float4(P.dir.x, P.dir.y, P.dir.z, __uint_as_float(pid));
+    q.c[slot] = make_float4(T.x, T.y, T.z, L.x);
+    q.d[slot] = make_float2(L.y, L.z);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample)
+{
+    __shared__ uint2 s_stack[kLdsStack * kBlock];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tiles_x = (F.width + 15u) >> 4;
+    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t k = blockIdx.y; // dispatch within this batch
+    const bool inside = px < F.width && py < F.height;
+    bool alive = false;
+    Payload P;
+    vec3 T = v3(1.0f, 1.0f, 1.0f), L = v3(0.0f, 0.0f, 0.0f);
+    uint32_t pid = 0;
+    if (inside)
+    {
+        const uint32_t pixel_index = py * F.width + px;
+        const uint32_t n_pixels = F.width * F.height;
+        pid = (k * B.spf + sample) * n_pixels + pixel_index;
+        P.rng = sample == 0u ? seed_(pixel_index, frame_first + (k_first + k) * F.frame_stride)
+                             : B.carry[k * n_pixels + pixel_index];
+        camera_ray(F, px, py, P.rng, P.origin, P.dir);
+        alive = F.max_depth > 0u;
+        if (alive)
+        {
+            const Hit h = trace_closest<false>(S, P.origin, P.dir, F.tmax, s_stack + threadIdx.x, kBlock, nullptr);
+            alive = shade_bounce(S, h, P, T, L) && F.max_depth > 1u;
+        }
+        if (!alive)
+        {
+            finish_path(B, pid, L, P.rng);
+        }
+    }
+    const uint32_t slot = queue_append(alive, &B.counts[1]);
+    if (alive)
+    {
+        store_state(B.q[1], slot, P, pid, T, L);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_wf_trace(DScene S, float tmax, WfState q, float4 *__restrict__ hit, uint2 *__restrict__ hit_ids,
+           const uint32_t *__restrict__ count)
+{
+    __shared__ uint2 s_stack[kLdsStack * kBlock];
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    {
+        const float4 a = q.a[i], b = q.b[i];
+        const Hit h = trace_closest<false>(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), tmax,
+                                           s_stack + threadIdx.x, kBlock, nullptr);
+        hit[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.flat));
+        hit_ids[i] = make_uint2(h.instance, h.primitive);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
+{
+    const WfState qi = B.q[src], qo = B.q[src ^ 1];
+    const uint32_t n = B.counts[bounce];
+    const uint32_t n_round = (n + 63u) & ~63u; // whole waves enter so ballots see every lane
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock)
+    {
+        bool alive = false;
+        Payload P;
+        vec3 T = v3(0.0f, 0.0f, 0.0f), L = T;
+        uint32_t pid = 0;
+        if (i < n)
+        {
+            const float4 a = qi.a[i], b = qi.b[i], c = qi.c[i];
+            const float2 d = qi.d[i];
+            const float4 hr = B.hit[i];
+            const uint2 hid = B.hit_ids[i];
+            P.origin = v3(a.x, a.y, a.z);
+            P.rng = __float_as_uint(a.w);
+            P.dir = v3(b.x, b.y, b.z);
+            pid = __float_as_uint(b.w);
+            T = v3(c.x, c.y, c.z);
+            L = v3(c.w, d.x, d.y);
+            Hit h;
+            h.t = hr.x;
+            h.u = hr.y;
+            h.v = hr.z;
+            h.flat = __float_as_uint(hr.w);
+            h.instance = hid.x;
+            h.primitive = hid.y;
+            alive = shade_bounce(S, h, P, T, L) && (bounce + 1u) < max_depth;
+            if (!alive)
+            {
+                finish_path(B, pid, L, P.rng);
+            }
+        }
+        const uint32_t slot = queue_append(alive, &B.counts[bounce + 1u]);
+        if (alive)
+        {
+            store_state(qo, slot, P, pid, T, L);
+        }
+    }
+}
+
+// Finishes every path still alive at `bounce` in one launch. Once few paths are
+// left, a launch pair per bounce costs more in launch latency than in work, so
+// the tail runs persistent: each lane pulls a live path from the queue (one
+// atomic per wave), walks it bounce by bounce to its end, then pulls the next,
+// which keeps the lanes of a wave busy until the queue is empty. Every wave
+// leaves the loop once the queue is exhausted and its own lanes are done.
+__global__ void __launch_bounds__(kBlock)
+k_wf_drain(DScene S, WfBuffers B, uint32_t bounce0, uint32_t max_depth, float tmax, int src,
+           uint32_t *__restrict__ head, DeviceStats *__restrict__ stats)
+{
+    __shared__ uint2 s_stack[kLdsStack * kBlock];
+    const WfState qi = B.q[src];
+    const uint32_t n = B.counts[bounce0];
+    const uint32_t lane = lane_id();
+    bool have = false;
+    Payload P;
+    vec3 T = v3(0.0f, 0.0f, 0.0f), L = T;
+    uint32_t pid = 0, bounce = 0, rays = 0;
+    for (;;)
+    {
+        const unsigned long long need = __ballot(!have);
+        if (need != 0ull)
+        {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(need);
+            const uint32_t leader = (uint32_t)__builtin_ctzll(need);
+            uint32_t base = 0;
+            if (lane == leader)
+            {
+                base = atomicAdd(head, cnt);
+            }
+            base = __shfl(base, (int)leader, 64);
+            const uint32_t i = base + (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+            if (!have && i < n)
+            {
+                const float4 a = qi.a[i], b = qi.b[i], c = qi.c[i];
+                const float2 d = qi.d[i];
+                P.origin = v3(a.x, a.y, a.z);
+                P.rng = __float_as_uint(a.w);
+                P.dir = v3(b.x, b.y, b.z);
+                pid = __float_as_uint(b.w);
+                T = v3(c.x, c.y, c.z);
+                L = v3(c.w, d.x, d.y);
+                bounce = bounce0;
+                have = true;
+            }
+        }
+        if (__ballot(have) == 0ull)
+        {
+            break;
+        }
+        if (have)
+        {
+            const Hit h = trace_closest<false>(S, P.origin, P.dir, tmax, s_stack + threadIdx.x, kBlock, nullptr);
+            ++rays;
+            const bool alive = shade_bounce(S, h, P, T, L) && (bounce + 1u) < max_depth;
+            ++bounce;
+            if (!alive)
+            {
+                finish_path(B, pid, L, P.rng);
+                have = false;
+            }
+        }
+    }
+    unsigned long long wr = rays;
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        wr += __shfl_xor(wr, off, 64);
+    }
+    if (lane == 0u && wr != 0ull)
+    {
+        atomicAdd(&stats->rays, wr);
+    }
+}
+
+// Per pixel: fold the batch's per-path radiances into the film in dispatch
+// order (shader.rgen:196, :202-223), then tone-map.
+__global__ void __launch_bounds__(kBlock)
+k_wf_resolve(DFrame F, const float4 *__restrict__ radiance, uint32_t n_disp, uint32_t spf,
+             uint32_t sample_count0, float4 *__restrict__ accum, uint32_t *__restrict__ rgba8)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n_pixels = F.width * F.height;
+    if (i >= n_pixels)
+    {
+        return;
+    }
+    float4 avg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t sample_count = sample_count0;
+    if (sample_count > 0u)
+    {
+        avg = accum[i];
+    }
+    // n_disp consecutive paths of this pixel; every spf of them form one dispatch
+    for (uint32_t k = 0; k < n_disp; k += spf)
+    {
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t s = 0; s < spf; ++s)
+        {
+            const float4 r = radiance[(size_t)(k + s) * n_pixels + i];
+            acc.x += r.x;
+            acc.y += r.y;
+            acc.z += r.z;
+            acc.w += 1.0f;
+        }
+        avg = accumulate(avg, acc, sample_count, spf, F.accumulate_sum != 0u);
+        sample_count += spf;
+    }
+    accum[i] = avg;
+    vec3 lin = v3(avg.x, avg.y, avg.z);
+    if (F.accumulate_sum != 0u)
+    {
+        lin = lin / avg.w;
+    }
+    rgba8[i] = pack_rgba8(lin);
+}
+
+// rays traced by the primary pass and by the trace launches of bounces [1, end_b)
+__global__ void k_wf_stats(const uint32_t *__restrict__ counts, uint32_t n_paths, uint32_t max_depth,
+                           uint32_t end_b, DeviceStats *__restrict__ stats)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+    {
+        unsigned long long rays = max_depth > 0u ? n_paths : 0u;
+        for (uint32_t b = 1; b < end_b; ++b)
+        {
+            rays += counts[b];
+        }
+        stats->rays += rays;
+        stats->paths += n_paths;
+    }
+}
+
+size_t align256(size_t x)
+{
+    return (x + 255) & ~(size_t)255;
+}
+
+} // namespace
+
+// Renders F.n_frames dispatches of F.samples_per_frame samples with ray queues.
+// Dispatches are independent (each re-seeds its RNG), so a batch of them is in
+// flight at once. The samples of one dispatch share an RNG stream, so they run
+// as successive passes, each pass starting from the state the previous sample
+// of the same pixel ended with.
+int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &F0)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t n_pixels = F0.width * F0.height;
+    const uint32_t spf = F0.samples_per_frame;
+    const uint32_t wf_bounces = F0.wavefront_bounces;
+    // dispatches per batch: bounded so the workspace stays modest (2^25 paths)
+    const uint32_t max_batch = std::max<uint32_t>(
+        1u, std::min<uint32_t>(F0.n_frames, (1u << 25) / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
+    const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
+    const size_t n_counts = (size_t)F0.max_depth + 2;
+    const size_t bytes = 2 * (align256(cap * 16) * 3 + align256(cap * 8)) + align256(cap * 16) + align256(cap * 8) +
+                         align256(cap * spf * 16) + align256(n_counts * 4) + align256(cap * 4);
+    if (bytes > ctx->wf_bytes)
+    {
+        PTC_HIP_CHECK(hipStreamSynchronize(st));
+        (void)hipFree(ctx->wf_buf);
+        ctx->wf_buf = nullptr;
+        ctx->wf_bytes = 0;
+        PTC_HIP_CHECK(hipMalloc(&ctx->wf_buf, bytes));
+        ctx->wf_bytes = bytes;
+    }
+    char *p = static_cast<char *>(ctx->wf_buf);
+    auto take = [&](size_t n) {
+        char *r = p;
+        p += align256(n);
+        return r;
+    };
+    WfBuffers B;
+    for (int k = 0; k < 2; ++k)
+    {
+        B.q[k].a = reinterpret_cast<float4 *>(take(cap * 16));
+        B.q[k].b = reinterpret_cast<float4 *>(take(cap * 16));
+        B.q[k].c = reinterpret_cast<float4 *>(take(cap * 16));
+        B.q[k].d = reinterpret_cast<float2 *>(take(cap * 8));
+    }
+    B.hit = reinterpret_cast<float4 *>(take(cap * 16));
+    B.hit_ids = reinterpret_cast<uint2 *>(take(cap * 8));
+    B.radiance = reinterpret_cast<float4 *>(take(cap * spf * 16));
+    B.counts = reinterpret_cast<uint32_t *>(take(n_counts * 4));
+    uint32_t *carry = reinterpret_cast<uint32_t *>(take(cap * 4));
+    B.carry = spf > 1u ? carry : nullptr;
+    B.spf = spf;
+    B.n_pixels = n_pixels;
+
+    const uint32_t tiles = ((F0.width + 15u) >> 4) * ((F0.height + 15u) >> 4);
+    const uint32_t persistent_blocks = (uint32_t)ctx->n_cus * 8u;
+    uint32_t sample_count = F0.sample_count;
+    for (uint32_t k0 = 0; k0 < F0.n_frames; k0 += max_batch)
+    {
+        const uint32_t nb = std::min(max_batch, F0.n_frames - k0);
+        const uint32_t n_paths = n_pixels * nb;
+        for (uint32_t s = 0; s < spf; ++s)
+        {
+            PTC_HIP_CHECK(hipMemsetAsync(B.counts, 0, n_counts * 4, st));
+            k_wf_primary<<<dim3(tiles, nb), kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0, s);
+            const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_paths + kBlock - 1) / kBlock);
+            // bounces [1, drain_b) as trace / shade launch pairs over compacted queues
+            const uint32_t drain_b = std::min(F0.max_depth, 1u + wf_bounces);
+            for (uint32_t b = 1; b < drain_b; ++b)
+            {
+                const int src = (int)(b & 1u); // the primary pass writes set 1
+                k_wf_trace<<<blocks, kBlock, 0, st>>>(scene->d, F0.tmax, B.q[src], B.hit, B.hit_ids, B.counts + b);
+                k_wf_shade<<<blocks, kBlock, 0, st>>>(scene->d, B, b, F0.max_depth, src);
+            }
+            // whatever is still alive runs to its end in one persistent launch
+            if (drain_b < F0.max_depth)
+            {
+                k_wf_drain<<<blocks, kBlock, 0, st>>>(scene->d, B, drain_b, F0.max_depth, F0.tmax, (int)(drain_b & 1u),
+                                                     B.counts + (F0.max_depth + 1u), ctx->d_stats);
+            }
+            k_wf_stats<<<1, 64, 0, st>>>(B.counts, n_paths, F0.max_depth, drain_b, ctx->d_stats);
+        }
+        k_wf_resolve<<<(n_pixels + kBlock - 1) / kBlock, kBlock, 0, st>>>(F0, B.radiance, nb * spf, spf, sample_count,
+                                                                         film->d_accum, film->d_rgba8);
+        sample_count += nb * spf;
+    }
+    PTC_HIP_CHECK(hipGetLastError());
+    return PTC_OK;
+}
+
 } // namespace ptc

@@ -95,7 +95,8 @@ class RenderParams(C.Structure):
                 ("n_frames", C.c_uint32), ("frame_stride", C.c_uint32),
                 ("max_depth", C.c_uint32), ("tmax", C.c_float),
                 ("integrator", C.c_uint32), ("accumulate", C.c_uint32),
-                ("instrument", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("instrument", C.c_uint32), ("wavefront_bounces", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
 
 
 class Stats(C.Structure):
@@ -438,6 +439,7 @@ class RenderResources:
         self.integrator = INTEGRATOR_MEGAKERNEL
         self.accumulate = ACCUM_RUNNING_MEAN
         self.instrument = False
+        self.wavefront_bounces = 0  # 0 = library default
 
     @property
     def sample_count(self) -> int:
@@ -459,6 +461,7 @@ class RenderResources:
         p.integrator = self.integrator
         p.accumulate = self.accumulate
         p.instrument = int(self.instrument)
+        p.wavefront_bounces = self.wavefront_bounces
         _check(lib().ptc_render(self.ctx.handle, self.scene.handle, self.film, C.byref(camera),
                                 C.byref(p)))
 

@@ -102,13 +102,16 @@ def test_primary_hit_ids(scene_pair, oracle):
         assert np.array_equal(ids, ref), f"{name}: {np.count_nonzero(ids != ref)} primary ids differ"
 
 
+@pytest.mark.parametrize("integrator", [R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT],
+                         ids=["megakernel", "wavefront"])
 @pytest.mark.parametrize("spf,n_frames", [(1, 3), (2, 2)])
-def test_render_bit_exact(scene_pair, ctx, oracle, spf, n_frames):
+def test_render_bit_exact(scene_pair, ctx, oracle, spf, n_frames, integrator):
     name, sc, dev, orc = scene_pair
     w, h = 80, 48
     cam = R.default_camera(w, h)
     rr = R.RenderResources(ctx, w, h, dev)
     rr.max_depth = 8
+    rr.integrator = integrator
     # two calls: a fresh film, then a continuation with sample_count > 0
     rr.render(cam, frame=5, samples_per_frame=spf, n_frames=n_frames)
     rr.render(cam, frame=5 + n_frames, samples_per_frame=spf, n_frames=1)
@@ -130,10 +133,13 @@ def test_ray_and_path_counters(ctx, oracle):
     w, h = 64, 64
     cam = R.default_camera(w, h)
     rr = R.RenderResources(ctx, w, h, dev)
-    ctx.reset_stats()
-    rr.render(cam, frame=0, n_frames=2)
-    st = ctx.stats()
     _, _, ref = orc.render(oracle.make_push(cam.as_dict()), w, h, n_frames=2, use_bvh=False)
-    assert (st.rays, st.paths) == (ref.rays, ref.paths)
+    for integrator in (R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT):
+        rr.integrator = integrator
+        R.reset_render(rr)
+        ctx.reset_stats()
+        rr.render(cam, frame=0, n_frames=2)
+        st = ctx.stats()
+        assert (st.rays, st.paths) == (ref.rays, ref.paths)
     rr.close()
     dev.close()
