@@ -883,7 +883,8 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
 
-    if (depth > (uint32_t)(kLdsStack + kSpillStack - 4))
+    // a traversal may hold two stack entries per level (siblings and postponed triangles)
+    if (2u * depth + 2u > (uint32_t)kStackTotal)
     {
         set_error("BVH build: wide tree deeper than the traversal stack");
         return PTC_E_LIMIT;

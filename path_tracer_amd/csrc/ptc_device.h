@@ -409,8 +409,8 @@ PTC_DEV uint32_t pack_rgba8(vec3 lin)
 constexpr float kDirEps = 8.673617379884035e-19f; // 2^-60
 constexpr float kSlabSlack = 1.0f / 262144.0f;     // 2^-18
 constexpr float kTLimitPad = 1.00006103515625f;    // 1 + 2^-14
-constexpr int kLdsStack = 12;                      // entries per lane kept in LDS
-constexpr int kSpillStack = 52;                    // further entries in scratch
+constexpr int kStackTotal = 64; // traversal stack entries per lane, LDS + scratch
+constexpr int kLdsStack = 8;    // default number of entries per lane kept in LDS
 
 PTC_DEV float clamp_dir(float d)
 {
@@ -455,149 +455,220 @@ PTC_DEV bool mt_test(vec3 o, vec3 d, vec3 v0, vec3 e1, vec3 e2, float tmax, floa
     return false;
 }
 
-// lds_stack: this lane's column of a [kLdsStack][blockDim.x] uint2 array, i.e.
-// entry e lives at lds_stack[e * stride].
-template <bool kCount>
+// Per-ray constants of a traversal.
+struct RayCtx
+{
+    vec3 o, d;
+    float idx, idy, idz; // 1 / direction, direction clamped away from zero
+    uint32_t octinv;     // 7 - octant; octant bit a set = direction negative on axis a
+    float tmax;
+};
+
+PTC_DEV RayCtx make_ray_ctx(vec3 o, vec3 d, float tmax)
+{
+    RayCtx R;
+    R.o = o;
+    R.d = d;
+    const float dcx = clamp_dir(d.x), dcy = clamp_dir(d.y), dcz = clamp_dir(d.z);
+    R.idx = 1.0f / dcx;
+    R.idy = 1.0f / dcy;
+    R.idz = 1.0f / dcz;
+    const uint32_t oct = (__float_as_uint(dcx) >> 31) | ((__float_as_uint(dcy) >> 31) << 1) |
+                         ((__float_as_uint(dcz) >> 31) << 2);
+    R.octinv = 7u - oct;
+    R.tmax = tmax;
+    return R;
+}
+
+PTC_DEV Hit no_hit(float tmax)
+{
+    Hit h;
+    h.t = tmax;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    h.flat = kNoHit;
+    h.instance = 0u;
+    h.primitive = 0u;
+    return h;
+}
+
+// A node group is (first internal child, hit bits 31..24 | imask 7..0): bit
+// 24 + (slot ^ octinv) set = that slot's box was hit and is still to be
+// visited; the highest bit is the nearest. A triangle group is (first triangle,
+// pending bits 23..0). The root is the group (0, 0x80000000).
+constexpr uint32_t kNodeBits = 0xff000000u;
+
+// Pops the nearest pending child off a node group; returns its node index.
+PTC_DEV uint32_t next_child(uint2 &ng, uint32_t octinv)
+{
+    const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng.y);
+    ng.y &= ~(1u << bit);
+    const uint32_t slot = (bit - 24u) ^ octinv;
+    return ng.x + (uint32_t)__builtin_popcount(ng.y & 0xffu & ((1u << slot) - 1u));
+}
+
+// Loads one wide node and tests its 8 child boxes against the ray; yields the
+// group of hit internal children and the group of triangles of hit leaf slots.
+PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t node_idx, uint2 &ng,
+                       uint2 &tg)
+{
+    const uint4 *__restrict__ N = S.nodes + 5u * (size_t)node_idx;
+    const uint4 w0 = N[0], w1 = N[1], w2 = N[2], w3 = N[3], w4 = N[4];
+    const uint32_t imask = w0.w >> 24;
+    const uint32_t octinv = R.octinv;
+    const bool negx = !(octinv & 1u), negy = !(octinv & 2u), negz = !(octinv & 4u);
+    const float sx = __uint_as_float((w0.w & 0xffu) << 23) * R.idx;
+    const float sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * R.idy;
+    const float sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * R.idz;
+    const float bx = (__uint_as_float(w0.x) - R.o.x) * R.idx;
+    const float by = (__uint_as_float(w0.y) - R.o.y) * R.idy;
+    const float bz = (__uint_as_float(w0.z) - R.o.z) * R.idz;
+    // per-axis slack: 2^-18 of the magnitudes entering each slab distance,
+    // subtracted from entry distances and added to exit distances
+    const float ex = __builtin_fmaf(255.0f, __builtin_fabsf(sx), __builtin_fabsf(bx)) * kSlabSlack;
+    const float ey = __builtin_fmaf(255.0f, __builtin_fabsf(sy), __builtin_fabsf(by)) * kSlabSlack;
+    const float ez = __builtin_fmaf(255.0f, __builtin_fabsf(sz), __builtin_fabsf(bz)) * kSlabSlack;
+    const float bnx = bx - ex, bny = by - ey, bnz = bz - ez;
+    const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez;
+    const float tlim = best_t * kTLimitPad;
+    // near / far plane bytes per axis, chosen by the ray's direction sign
+    const uint32_t nx0 = negx ? w3.z : w2.x, nx1 = negx ? w3.w : w2.y;
+    const uint32_t fx0 = negx ? w2.x : w3.z, fx1 = negx ? w2.y : w3.w;
+    const uint32_t ny0 = negy ? w4.x : w2.z, ny1 = negy ? w4.y : w2.w;
+    const uint32_t fy0 = negy ? w2.z : w4.x, fy1 = negy ? w2.w : w4.y;
+    const uint32_t nz0 = negz ? w4.z : w3.x, nz1 = negz ? w4.w : w3.y;
+    const uint32_t fz0 = negz ? w3.x : w4.z, fz1 = negz ? w3.y : w4.w;
+    uint32_t hitmask = 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+    {
+        const uint32_t meta = ((c < 4 ? w1.z : w1.w) >> (8 * (c & 3))) & 0xffu;
+        const float qnx = ubyte_f(c < 4 ? nx0 : nx1, c & 3);
+        const float qny = ubyte_f(c < 4 ? ny0 : ny1, c & 3);
+        const float qnz = ubyte_f(c < 4 ? nz0 : nz1, c & 3);
+        const float qfx = ubyte_f(c < 4 ? fx0 : fx1, c & 3);
+        const float qfy = ubyte_f(c < 4 ? fy0 : fy1, c & 3);
+        const float qfz = ubyte_f(c < 4 ? fz0 : fz1, c & 3);
+        // (slab distances are finite for finite input, so the hardware min / max
+        // and the compare-select forms agree)
+        float tn = __builtin_fmaxf(0.0f, __builtin_fmaf(qnx, sx, bnx));
+        tn = __builtin_fmaxf(tn, __builtin_fmaf(qny, sy, bny));
+        tn = __builtin_fmaxf(tn, __builtin_fmaf(qnz, sz, bnz));
+        float tf = __builtin_fminf(tlim, __builtin_fmaf(qfx, sx, bfx));
+        tf = __builtin_fminf(tf, __builtin_fmaf(qfy, sy, bfy));
+        tf = __builtin_fminf(tf, __builtin_fmaf(qfz, sz, bfz));
+        if (meta != 0u && tn <= tf)
+        {
+            if ((imask >> c) & 1u)
+            {
+                hitmask |= 1u << (24u + ((uint32_t)c ^ octinv));
+            }
+            else
+            {
+                hitmask |= (meta >> 5) << (meta & 31u);
+            }
+        }
+    }
+    ng.x = w1.x;
+    ng.y = (hitmask & kNodeBits) | imask;
+    tg.x = w1.y;
+    tg.y = hitmask & ~kNodeBits;
+}
+
+// Tests one triangle and keeps it if it beats the best hit in (t, flat) order.
+PTC_DEV void tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index, Hit &best)
+{
+    const float4 *__restrict__ T = S.tris + 3u * (size_t)tri_index;
+    const float4 a = T[0], b = T[1], c = T[2];
+    float t, u, v;
+    if (mt_test(R.o, R.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), R.tmax, t, u, v))
+    {
+        const uint32_t flat = __float_as_uint(c.w);
+        if (t < best.t || (t == best.t && flat < best.flat))
+        {
+            best.t = t;
+            best.u = u;
+            best.v = v;
+            best.flat = flat;
+            best.instance = __float_as_uint(a.w);
+            best.primitive = __float_as_uint(b.w);
+        }
+    }
+}
+
+// Traversal stack: the first kLdsStack entries of a lane live in LDS (entry e
+// of the lane at lds[e * stride]), deeper ones in a private spill array. The
+// pieces are passed separately (not as one struct) so that the depth counter
+// stays in a register and the LDS pointer keeps its address space.
+template <int kLds>
+PTC_DEV void stack_push(uint2 *lds, uint32_t stride, uint2 *spill, int &sp, uint2 e)
+{
+    if (sp < kLds)
+    {
+        lds[sp * stride] = e;
+    }
+    else if (sp < kStackTotal)
+    {
+        spill[sp - kLds] = e;
+    }
+    ++sp;
+}
+
+template <int kLds>
+PTC_DEV uint2 stack_pop(const uint2 *lds, uint32_t stride, const uint2 *spill, int &sp)
+{
+    --sp;
+    return sp < kLds ? lds[sp * stride] : spill[sp - kLds];
+}
+
+// Closest hit of one ray, in a fixed order: visit the nearest pending child,
+// test the triangles of its hit leaf slots at once, descend. (This order is the
+// one a scalar re-implementation can follow, so node and triangle counts are
+// reproducible.)
+template <bool kCount, int kLds = kLdsStack>
 PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_stack,
                           uint32_t stride, TraceCounters *ctr)
 {
-    Hit best;
-    best.t = tmax;
-    best.u = 0.0f;
-    best.v = 0.0f;
-    best.flat = kNoHit;
-    best.instance = 0u;
-    best.primitive = 0u;
+    Hit best = no_hit(tmax);
     if (S.n_tris == 0u)
     {
         return best;
     }
-    const float dcx = clamp_dir(d.x), dcy = clamp_dir(d.y), dcz = clamp_dir(d.z);
-    const float idx = 1.0f / dcx, idy = 1.0f / dcy, idz = 1.0f / dcz;
-    const bool negx = (__float_as_uint(dcx) >> 31) != 0u;
-    const bool negy = (__float_as_uint(dcy) >> 31) != 0u;
-    const bool negz = (__float_as_uint(dcz) >> 31) != 0u;
-    const uint32_t oct = (negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u);
-    const uint32_t octinv = 7u - oct;
-
-    uint2 spill[kSpillStack];
+    const RayCtx R = make_ray_ctx(o, d, tmax);
+    uint2 spill[kStackTotal - kLds];
     int sp = 0;
-    uint32_t node_idx = 0u;
+    uint2 ng = make_uint2(0u, 0x80000000u);
     for (;;)
     {
-        const uint4 *__restrict__ N = S.nodes + 5u * (size_t)node_idx;
-        const uint4 w0 = N[0], w1 = N[1], w2 = N[2], w3 = N[3], w4 = N[4];
+        const uint32_t node_idx = next_child(ng, R.octinv);
+        if (ng.y & kNodeBits)
+        {
+            stack_push<kLds>(lds_stack, stride, spill, sp, ng);
+        }
+        uint2 tg;
+        node_test(S, R, best.t, node_idx, ng, tg);
         if (kCount)
         {
             ctr->nodes++;
         }
-        const uint32_t imask = w0.w >> 24;
-        const float sx = __uint_as_float((w0.w & 0xffu) << 23) * idx;
-        const float sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * idy;
-        const float sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * idz;
-        const float bx = (__uint_as_float(w0.x) - o.x) * idx;
-        const float by = (__uint_as_float(w0.y) - o.y) * idy;
-        const float bz = (__uint_as_float(w0.z) - o.z) * idz;
-        // per-axis slack: 2^-18 of the magnitudes entering each slab distance,
-        // subtracted from entry distances and added to exit distances
-        const float ex = __builtin_fmaf(255.0f, __builtin_fabsf(sx), __builtin_fabsf(bx)) * kSlabSlack;
-        const float ey = __builtin_fmaf(255.0f, __builtin_fabsf(sy), __builtin_fabsf(by)) * kSlabSlack;
-        const float ez = __builtin_fmaf(255.0f, __builtin_fabsf(sz), __builtin_fabsf(bz)) * kSlabSlack;
-        const float bnx = bx - ex, bny = by - ey, bnz = bz - ez;
-        const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez;
-        const float tlim = best.t * kTLimitPad;
-        // near / far plane bytes per axis, chosen by the ray's direction sign
-        const uint32_t nx0 = negx ? w3.z : w2.x, nx1 = negx ? w3.w : w2.y;
-        const uint32_t fx0 = negx ? w2.x : w3.z, fx1 = negx ? w2.y : w3.w;
-        const uint32_t ny0 = negy ? w4.x : w2.z, ny1 = negy ? w4.y : w2.w;
-        const uint32_t fy0 = negy ? w2.z : w4.x, fy1 = negy ? w2.w : w4.y;
-        const uint32_t nz0 = negz ? w4.z : w3.x, nz1 = negz ? w4.w : w3.y;
-        const uint32_t fz0 = negz ? w3.x : w4.z, fz1 = negz ? w3.y : w4.w;
-        uint32_t hitmask = 0u;
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
+        while (tg.y)
         {
-            const uint32_t meta = ((c < 4 ? w1.z : w1.w) >> (8 * (c & 3))) & 0xffu;
-            const float qnx = ubyte_f(c < 4 ? nx0 : nx1, c & 3);
-            const float qny = ubyte_f(c < 4 ? ny0 : ny1, c & 3);
-            const float qnz = ubyte_f(c < 4 ? nz0 : nz1, c & 3);
-            const float qfx = ubyte_f(c < 4 ? fx0 : fx1, c & 3);
-            const float qfy = ubyte_f(c < 4 ? fy0 : fy1, c & 3);
-            const float qfz = ubyte_f(c < 4 ? fz0 : fz1, c & 3);
-            float tn = fmax_(0.0f, __builtin_fmaf(qnx, sx, bnx));
-            tn = fmax_(tn, __builtin_fmaf(qny, sy, bny));
-            tn = fmax_(tn, __builtin_fmaf(qnz, sz, bnz));
-            float tf = fmin_(tlim, __builtin_fmaf(qfx, sx, bfx));
-            tf = fmin_(tf, __builtin_fmaf(qfy, sy, bfy));
-            tf = fmin_(tf, __builtin_fmaf(qfz, sz, bfz));
-            if (meta != 0u && tn <= tf)
-            {
-                if ((imask >> c) & 1u)
-                {
-                    hitmask |= 1u << (24u + ((uint32_t)c ^ octinv));
-                }
-                else
-                {
-                    hitmask |= (meta >> 5) << (meta & 31u);
-                }
-            }
-        }
-        uint2 ng;
-        ng.x = w1.x;
-        ng.y = (hitmask & 0xff000000u) | imask;
-        uint32_t tbits = hitmask & 0x00ffffffu;
-        const uint32_t tri_base = w1.y;
-        while (tbits)
-        {
-            const uint32_t i = (uint32_t)__builtin_ctz(tbits);
-            tbits &= tbits - 1u;
-            const float4 *__restrict__ T = S.tris + 3u * (size_t)(tri_base + i);
-            const float4 a = T[0], b = T[1], c = T[2];
+            const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
+            tg.y &= tg.y - 1u;
+            tri_test(S, R, tg.x + i, best);
             if (kCount)
             {
                 ctr->tris++;
             }
-            float t, u, v;
-            if (mt_test(o, d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), tmax, t,
-                        u, v))
-            {
-                const uint32_t flat = __float_as_uint(c.w);
-                if (t < best.t || (t == best.t && flat < best.flat))
-                {
-                    best.t = t;
-                    best.u = u;
-                    best.v = v;
-                    best.flat = flat;
-                    best.instance = __float_as_uint(a.w);
-                    best.primitive = __float_as_uint(b.w);
-                }
-            }
         }
-        if (!(ng.y & 0xff000000u))
+        if (!(ng.y & kNodeBits))
         {
             if (sp == 0)
             {
                 break;
             }
-            --sp;
-            ng = sp < kLdsStack ? lds_stack[sp * stride] : spill[sp - kLdsStack];
+            ng = stack_pop<kLds>(lds_stack, stride, spill, sp);
         }
-        const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng.y);
-        ng.y &= ~(1u << bit);
-        const uint32_t slot = (bit - 24u) ^ octinv;
-        if (ng.y & 0xff000000u)
-        {
-            if (sp < kLdsStack)
-            {
-                lds_stack[sp * stride] = ng;
-            }
-            else if (sp < kLdsStack + kSpillStack)
-            {
-                spill[sp - kLdsStack] = ng;
-            }
-            ++sp;
-        }
-        node_idx = ng.x + (uint32_t)__builtin_popcount(ng.y & 0xffu & ((1u << slot) - 1u));
     }
     return best;
 }

@@ -241,33 +241,51 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
 // atomic per wave), walks it bounce by bounce to its end, then pulls the next,
 // which keeps the lanes of a wave busy until the queue is empty. Every wave
 // leaves the loop once the queue is exhausted and its own lanes are done.
-__global__ void __launch_bounds__(kBlock)
+constexpr int kDrainLds = 16; // LDS stack entries per lane in the drain kernel (two pushes per level)
+__global__ void __launch_bounds__(kBlock, 5)
 k_wf_drain(DScene S, WfBuffers B, uint32_t bounce0, uint32_t max_depth, float tmax, int src,
            uint32_t *__restrict__ head, DeviceStats *__restrict__ stats)
 {
-    __shared__ uint2 s_stack[kLdsStack * kBlock];
+    __shared__ uint2 s_stack[kDrainLds * kBlock];
     const WfState qi = B.q[src];
     const uint32_t n = B.counts[bounce0];
     const uint32_t lane = lane_id();
-    bool have = false;
+    // Lane state machine. A lane is idle (kIdle), walking the tree for its
+    // path's current ray (kTrav), or has its closest hit and waits to be shaded
+    // (kShade). Every loop iteration runs at most one node visit per lane, so
+    // lanes with short and long traversals do not wait for each other; the
+    // rarer phases (pulling new paths, shading, triangle tests) run when
+    // enough lanes of the wave want them, or when a lane has nothing else left.
+    constexpr uint32_t kIdle = 0u, kTrav = 1u, kShade = 2u;
+    constexpr uint32_t kFetchMin = 8u, kShadeMin = 16u; // lanes that must want a phase before it runs
+    uint32_t mode = kIdle;
+    bool exhausted = n == 0u;
     Payload P;
     vec3 T = v3(0.0f, 0.0f, 0.0f), L = T;
     uint32_t pid = 0, bounce = 0, rays = 0;
+    RayCtx R = make_ray_ctx(v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f), tmax);
+    Hit best = no_hit(tmax);
+    uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    uint2 *const lds = s_stack + threadIdx.x;
+    uint2 spill[kStackTotal - kDrainLds];
+    int sp = 0;
     for (;;)
     {
-        const unsigned long long need = __ballot(!have);
-        if (need != 0ull)
+        const unsigned long long trav = __ballot(mode == kTrav);
+        // ---- pull new paths for idle lanes
+        const unsigned long long need = __ballot(mode == kIdle);
+        const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
+        if (!exhausted && n_need != 0u && (n_need >= kFetchMin || trav == 0ull))
         {
-            const uint32_t cnt = (uint32_t)__builtin_popcountll(need);
             const uint32_t leader = (uint32_t)__builtin_ctzll(need);
             uint32_t base = 0;
             if (lane == leader)
             {
-                base = atomicAdd(head, cnt);
+                base = atomicAdd(head, n_need);
             }
             base = __shfl(base, (int)leader, 64);
             const uint32_t i = base + (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
-            if (!have && i < n)
+            if (mode == kIdle && i < n)
             {
                 const float4 a = qi.a[i], b = qi.b[i], c = qi.c[i];
                 const float2 d = qi.d[i];
@@ -278,24 +296,87 @@ k_wf_drain(DScene S, WfBuffers B, uint32_t bounce0, uint32_t max_depth, float tm
                 T = v3(c.x, c.y, c.z);
                 L = v3(c.w, d.x, d.y);
                 bounce = bounce0;
-                have = true;
+                R = make_ray_ctx(P.origin, P.dir, tmax);
+                best = no_hit(tmax);
+                ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
+                tg = make_uint2(0u, 0u);
+                sp = 0;
+                mode = kTrav;
+                ++rays;
+            }
+            exhausted = base + n_need >= n; // wave-uniform: base and n_need are
+        }
+        // ---- shade lanes whose traversal is complete
+        const unsigned long long shade = __ballot(mode == kShade);
+        const uint32_t n_shade = (uint32_t)__builtin_popcountll(shade);
+        if (n_shade != 0u && (n_shade >= kShadeMin || __ballot(mode == kTrav) == 0ull))
+        {
+            if (mode == kShade)
+            {
+                const bool alive = shade_bounce(S, best, P, T, L) && (bounce + 1u) < max_depth;
+                ++bounce;
+                if (alive)
+                {
+                    R = make_ray_ctx(P.origin, P.dir, tmax);
+                    best = no_hit(tmax);
+                    ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
+                    tg = make_uint2(0u, 0u);
+                    sp = 0;
+                    mode = kTrav;
+                    ++rays;
+                }
+                else
+                {
+                    finish_path(B, pid, L, P.rng);
+                    mode = kIdle;
+                }
             }
         }
-        if (__ballot(have) == 0ull)
+        if (exhausted && __ballot(mode != kIdle) == 0ull)
         {
             break;
         }
-        if (have)
+        // ---- out of local work: pop the stack, or the traversal is complete
+        if (mode == kTrav && !(ng.y & kNodeBits) && tg.y == 0u)
         {
-            const Hit h = trace_closest<false>(S, P.origin, P.dir, tmax, s_stack + threadIdx.x, kBlock, nullptr);
-            ++rays;
-            const bool alive = shade_bounce(S, h, P, T, L) && (bounce + 1u) < max_depth;
-            ++bounce;
-            if (!alive)
+            if (sp == 0)
             {
-                finish_path(B, pid, L, P.rng);
-                have = false;
+                mode = kShade;
             }
+            else
+            {
+                const uint2 e = stack_pop<kDrainLds>(lds, kBlock, spill, sp);
+                if (e.y & kNodeBits)
+                {
+                    ng = e;
+                }
+                else
+                {
+                    tg = e;
+                }
+            }
+        }
+        // ---- one node visit for every lane that has one pending
+        if (mode == kTrav && (ng.y & kNodeBits))
+        {
+            const uint32_t node_idx = next_child(ng, R.octinv);
+            if (ng.y & kNodeBits)
+            {
+                stack_push<kDrainLds>(lds, kBlock, spill, sp, ng);
+            }
+            if (tg.y)
+            {
+                stack_push<kDrainLds>(lds, kBlock, spill, sp, tg); // triangles found earlier and not tested yet
+            }
+            node_test(S, R, best.t, node_idx, ng, tg);
+        }
+        // ---- at most one triangle test per lane and iteration, so that lanes with
+        // many pending triangles do not hold the wave
+        if (mode == kTrav && tg.y != 0u)
+        {
+            const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
+            tg.y &= tg.y - 1u;
+            tri_test(S, R, tg.x + i, best);
         }
     }
     unsigned long long wr = rays;
@@ -385,9 +466,9 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     const uint32_t n_pixels = F0.width * F0.height;
     const uint32_t spf = F0.samples_per_frame;
     const uint32_t wf_bounces = F0.wavefront_bounces;
-    // dispatches per batch: bounded so the workspace stays modest (2^25 paths)
+    // dispatches per batch: bounded so the workspace stays bounded (2^27 paths, about 23 GB)
     const uint32_t max_batch = std::max<uint32_t>(
-        1u, std::min<uint32_t>(F0.n_frames, (1u << 25) / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
+        1u, std::min<uint32_t>(F0.n_frames, (1u << 27) / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
     const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
     const size_t n_counts = (size_t)F0.max_depth + 2;
     const size_t bytes = 2 * (align256(cap * 16) * 3 + align256(cap * 8)) + align256(cap * 16) + align256(cap * 8) +
@@ -425,7 +506,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     B.n_pixels = n_pixels;
 
     const uint32_t tiles = ((F0.width + 15u) >> 4) * ((F0.height + 15u) >> 4);
-    const uint32_t persistent_blocks = (uint32_t)ctx->n_cus * 8u;
+    const uint32_t persistent_blocks = (uint32_t)ctx->n_cus * 6u;
     uint32_t sample_count = F0.sample_count;
     for (uint32_t k0 = 0; k0 < F0.n_frames; k0 += max_batch)
     {
