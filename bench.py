@@ -82,9 +82,9 @@ def cpu_baseline(scene, cam, width, height, max_depth, seconds_target: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--scene", default="dragon")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -140,13 +140,23 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # instrumented pass (untimed): nodes / triangles / hits per ray for the roofline
-    rr.instrument = True
-    ctx.reset_stats()
-    step(0)
-    ctx.synchronize()
-    inst = ctx.stats()
-    rr.instrument = False
+    # Instrumented passes (untimed, megakernel with counters: same rays, same
+    # visit order as the oracle's traversal of this BVH): BVH nodes visited and
+    # triangles tested for all rays and for the first bounce alone; the
+    # difference is what the persistent drain launch has to fetch.
+    def instrumented(depth):
+        rr.integrator, rr.instrument, rr.max_depth = R.INTEGRATOR_MEGAKERNEL, True, depth
+        R.reset_render(rr)
+        ctx.reset_stats()
+        step(0)
+        ctx.synchronize()
+        st_ = ctx.stats()
+        return st_.rays, st_.paths, st_.nodes_visited, st_.tris_tested
+
+    inst_all = instrumented(args.max_depth)
+    inst_first = instrumented(1)
+    rr.instrument, rr.max_depth = False, args.max_depth
+    rr.integrator = R.INTEGRATOR_WAVEFRONT if args.integrator == "wavefront" else R.INTEGRATOR_MEGAKERNEL
     R.reset_render(rr)
 
     for k in range(args.warmup):
@@ -154,6 +164,7 @@ def main():
     R.reset_render(rr)
     ctx.reset_stats()
     ctx.render_times()
+    ctx.phase_times()
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -165,7 +176,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = ctx.stats()
-    kernel_ms = ctx.render_times()
+    phases = ctx.phase_times()  # HIP events recorded inside the timed region
     t = torch.tensor([elapsed, float(st.rays), float(st.paths)], dtype=torch.float64,
                      device=f"cuda:{local_rank}")
     if world > 1:
@@ -182,14 +193,29 @@ def main():
             if msg:
                 print(msg, file=sys.stderr)
         total_spp = args.steps * spp * world
-        # roofline of the dominant kernel (the render kernel), per launch
-        rays_l = inst.rays
-        paths_l = inst.paths
-        hits_l = rays_l - paths_l  # upper bound: every non-final ray shades a hit
-        alg_bytes = (inst.nodes_visited * B_NODE + inst.tris_tested * B_TRI + hits_l * B_HIT +
-                     paths_l * B_MISS + W * H * spp * B_PIXEL)
-        avg_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        rays_a, paths_a, nodes_a, tris_a = inst_all
+        rays_f, _, nodes_f, tris_f = inst_first
+        # dominant kernel: the one with the largest share of device time
+        dom = max(phases, key=lambda k: phases[k][0])
+        dom_ms, dom_n = phases[dom]
+        if dom == "drain":
+            # bounces >= 1 only: the rays, nodes and triangles beyond the first bounce
+            rays_d, nodes_d, tris_d = rays_a - rays_f, nodes_a - nodes_f, tris_a - tris_f
+            # every such ray ends in a shaded hit (84 B gather) or a sky lookup (64 B)
+            alg_bytes = nodes_d * B_NODE + tris_d * B_TRI + rays_d * B_HIT
+        else:
+            rays_d, nodes_d, tris_d = rays_a, nodes_a, tris_a
+            alg_bytes = (nodes_d * B_NODE + tris_d * B_TRI + (rays_a - paths_a) * B_HIT + paths_a * B_MISS +
+                         W * H * spp * B_PIXEL)
+        launches_per_step = max(dom_n // max(args.steps, 1), 1)
+        avg_ms = dom_ms / max(dom_n, 1)
+        achieved = alg_bytes / launches_per_step / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else float("nan")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("kernel") == dom and tj.get("spp_per_step") == spp and tj.get("scene") == args.scene:
+                traffic = tj.get("hbm_bytes_per_launch")
         out = {
             "metric": "Mrays/s (whole node), dragon 1080p", "value": round(total_rays / elapsed / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,13 +229,16 @@ def main():
                        "triangles": info.n_triangles, "bvh_nodes": info.n_nodes,
                        "bvh_build_ms": round(info.build_ms, 2), "bvh_sah_cost": round(info.sah_cost, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "render", "avg_launch_ms": round(avg_ms, 3),
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "nodes_per_ray": round(inst.nodes_visited / max(rays_l, 1), 2),
-                         "tris_per_ray": round(inst.tris_tested / max(rays_l, 1), 2),
-                         "note": "working set is Infinity-Cache resident; HBM peak is the stated "
-                                 "bound, not the level that serves the fetches"},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": dom, "avg_launch_ms": round(avg_ms, 3),
+                         "launches_per_step": launches_per_step,
+                         "algorithmic_bytes_per_launch": int(alg_bytes / launches_per_step),
+                         "rays_per_launch": int(rays_d / launches_per_step),
+                         "nodes_per_ray": round(nodes_d / max(rays_d, 1), 2),
+                         "tris_per_ray": round(tris_d / max(rays_d, 1), 2),
+                         "phase_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in phases.items() if v[1]},
+                         "note": "working set (52 MB) is Infinity-Cache resident; HBM peak is the "
+                                 "stated bound, not the level that serves the fetches"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, W, H, args.max_depth, args.cpu_seconds)

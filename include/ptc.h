@@ -256,6 +256,16 @@ int ptc_get_stats(ptc_context *ctx, ptc_stats *out);
  * calls issued since the last call of this function, oldest first, at most
  * 256 kept. Synchronises the stream. *n_out receives the number written. */
 int ptc_render_times(ptc_context *ctx, double *ms_out, size_t capacity, size_t *n_out);
+/* Device time per kernel phase, summed over the ptc_render calls since the
+ * last call of this function (HIP events on the context's stream; synchronises).
+ * ms_out / launches_out: PTC_N_PHASES entries each. */
+#define PTC_PHASE_MEGAKERNEL 0u /* k_render_mega */
+#define PTC_PHASE_PRIMARY 1u    /* fused first bounce of the wavefront integrator */
+#define PTC_PHASE_BOUNCE 2u     /* traversal + shading launch pairs */
+#define PTC_PHASE_DRAIN 3u      /* persistent launch finishing all live paths */
+#define PTC_PHASE_RESOLVE 4u    /* accumulate + tone map */
+#define PTC_N_PHASES 5u
+int ptc_phase_times(ptc_context *ctx, double *ms_out, uint32_t *launches_out);
 int ptc_reset_stats(ptc_context *ctx);
 int ptc_synchronize(ptc_context *ctx);
 

@@ -249,6 +249,11 @@ void ptc_context_destroy(ptc_context *ctx)
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
     }
+    for (auto &e : ctx->phase_pool)
+    {
+        (void)hipEventDestroy(e.start);
+        (void)hipEventDestroy(e.stop);
+    }
     if (ctx->own_stream)
     {
         (void)hipStreamDestroy(ctx->stream);
@@ -917,6 +922,38 @@ int ptc_render_times(ptc_context *ctx, double *ms_out, size_t capacity, size_t *
     }
     ctx->ev_used = 0;
     *n_out = n;
+    return PTC_OK;
+}
+
+int ptc_phase_times(ptc_context *ctx, double *ms_out, uint32_t *launches_out)
+{
+    if (!ctx || !ms_out || !launches_out)
+    {
+        set_error("ptc_phase_times: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (use_device(ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t k = 0; k < PTC_N_PHASES; ++k)
+    {
+        ms_out[k] = 0.0;
+        launches_out[k] = 0;
+    }
+    for (size_t i = 0; i < ctx->phase_used; ++i)
+    {
+        const auto &e = ctx->phase_pool[i];
+        float ms = 0.0f;
+        PTC_HIP_CHECK(hipEventElapsedTime(&ms, e.start, e.stop));
+        if (e.tag < PTC_N_PHASES)
+        {
+            ms_out[e.tag] += ms;
+            launches_out[e.tag] += 1;
+        }
+    }
+    ctx->phase_used = 0;
     return PTC_OK;
 }
 

@@ -47,6 +47,14 @@ struct ptc_context
     double last_render_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; // one pair per recorded render
     size_t ev_used = 0;
+    // event pairs around the kernel phases of the renders, tagged PTC_PHASE_*
+    struct PhaseEvent
+    {
+        hipEvent_t start, stop;
+        uint32_t tag;
+    };
+    std::vector<PhaseEvent> phase_pool;
+    size_t phase_used = 0;
     int n_cus = 256;
     // wavefront integrator workspace, grown on demand
     void *wf_buf = nullptr;
@@ -79,6 +87,40 @@ struct ptc_film
 
 namespace ptc
 {
+
+// Brackets one kernel phase of a render with events (at most 1024 are kept
+// between two ptc_phase_times() calls; later ones go untimed).
+struct PhaseTimer
+{
+    ptc_context *ctx;
+    hipEvent_t stop = nullptr;
+    PhaseTimer(ptc_context *c, uint32_t tag) : ctx(c)
+    {
+        if (ctx->phase_used == ctx->phase_pool.size() && ctx->phase_pool.size() < 1024)
+        {
+            ptc_context::PhaseEvent e{};
+            if (hipEventCreate(&e.start) != hipSuccess || hipEventCreate(&e.stop) != hipSuccess)
+            {
+                return;
+            }
+            ctx->phase_pool.push_back(e);
+        }
+        if (ctx->phase_used < ctx->phase_pool.size())
+        {
+            ptc_context::PhaseEvent &e = ctx->phase_pool[ctx->phase_used++];
+            e.tag = tag;
+            (void)hipEventRecord(e.start, ctx->stream);
+            stop = e.stop;
+        }
+    }
+    ~PhaseTimer()
+    {
+        if (stop)
+        {
+            (void)hipEventRecord(stop, ctx->stream);
+        }
+    }
+};
 
 // BVH build on the device (ptc_bvh_build.hip). Fills scene->d_nodes, d_tris,
 // d.nodes, d.tris and the BVH fields of scene->info.

@@ -194,6 +194,7 @@ int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
                        bool count)
 {
     const uint32_t tiles = ((F.width + 15u) >> 4) * ((F.height + 15u) >> 4);
+    PhaseTimer timer(ctx, PTC_PHASE_MEGAKERNEL);
     if (count)
     {
         k_render_mega<true><<<tiles, kBlock, 0, ctx->stream>>>(scene->d, F, film->d_accum, film->d_rgba8,

@@ -515,12 +515,16 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
         for (uint32_t s = 0; s < spf; ++s)
         {
             PTC_HIP_CHECK(hipMemsetAsync(B.counts, 0, n_counts * 4, st));
-            k_wf_primary<<<dim3(tiles, nb), kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0, s);
+            {
+                PhaseTimer timer(ctx, PTC_PHASE_PRIMARY);
+                k_wf_primary<<<dim3(tiles, nb), kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0, s);
+            }
             const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_paths + kBlock - 1) / kBlock);
             // bounces [1, drain_b) as trace / shade launch pairs over compacted queues
             const uint32_t drain_b = std::min(F0.max_depth, 1u + wf_bounces);
             for (uint32_t b = 1; b < drain_b; ++b)
             {
+                PhaseTimer timer(ctx, PTC_PHASE_BOUNCE);
                 const int src = (int)(b & 1u); // the primary pass writes set 1
                 k_wf_trace<<<blocks, kBlock, 0, st>>>(scene->d, F0.tmax, B.q[src], B.hit, B.hit_ids, B.counts + b);
                 k_wf_shade<<<blocks, kBlock, 0, st>>>(scene->d, B, b, F0.max_depth, src);
@@ -528,13 +532,17 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             // whatever is still alive runs to its end in one persistent launch
             if (drain_b < F0.max_depth)
             {
+                PhaseTimer timer(ctx, PTC_PHASE_DRAIN);
                 k_wf_drain<<<blocks, kBlock, 0, st>>>(scene->d, B, drain_b, F0.max_depth, F0.tmax, (int)(drain_b & 1u),
                                                      B.counts + (F0.max_depth + 1u), ctx->d_stats);
             }
             k_wf_stats<<<1, 64, 0, st>>>(B.counts, n_paths, F0.max_depth, drain_b, ctx->d_stats);
         }
-        k_wf_resolve<<<(n_pixels + kBlock - 1) / kBlock, kBlock, 0, st>>>(F0, B.radiance, nb * spf, spf, sample_count,
-                                                                         film->d_accum, film->d_rgba8);
+        {
+            PhaseTimer timer(ctx, PTC_PHASE_RESOLVE);
+            k_wf_resolve<<<(n_pixels + kBlock - 1) / kBlock, kBlock, 0, st>>>(F0, B.radiance, nb * spf, spf, sample_count,
+                                                                             film->d_accum, film->d_rgba8);
+        }
         sample_count += nb * spf;
     }
     PTC_HIP_CHECK(hipGetLastError());

@@ -114,6 +114,7 @@ EXPORTS = [
     "ptc_film_set_sample_count", "ptc_film_read_accum", "ptc_film_read_rgba8",
     "ptc_film_accum_device_ptr", "ptc_film_resolve", "ptc_render", "ptc_primary_hits",
     "ptc_trace_rays", "ptc_trace_rays_device", "ptc_get_stats", "ptc_render_times",
+    "ptc_phase_times",
     "ptc_reset_stats",
     "ptc_synchronize", "ptc_write_png", "ptc_math_eval",
 ]
@@ -157,6 +158,7 @@ def lib():
         L.ptc_trace_rays_device.argtypes = [vp, vp, vp, sz, f32, vp]
         L.ptc_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.ptc_render_times.argtypes = [vp, vp, sz, C.POINTER(sz)]
+        L.ptc_phase_times.argtypes = [vp, vp, vp]
         L.ptc_reset_stats.argtypes = [vp]
         L.ptc_synchronize.argtypes = [vp]
         L.ptc_write_png.argtypes = [vp, C.c_char_p]
@@ -310,6 +312,15 @@ class RenderContext:
         n = C.c_size_t(0)
         _check(lib().ptc_render_times(self.handle, out.ctypes.data, out.size, C.byref(n)))
         return out[: n.value].copy()
+
+    PHASES = ("megakernel", "primary", "bounce", "drain", "resolve")
+
+    def phase_times(self) -> dict:
+        """{phase: (device ms, launches)} summed over the renders since the last call."""
+        ms = np.zeros(len(self.PHASES), np.float64)
+        n = np.zeros(len(self.PHASES), np.uint32)
+        _check(lib().ptc_phase_times(self.handle, ms.ctypes.data, n.ctypes.data))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.PHASES)}
 
     def math_eval(self, fn: int, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float32)
