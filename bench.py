@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-depth", type=int, default=32)
-    ap.add_argument("--integrator", default="wavefront", choices=["megakernel", "wavefront"])
+    ap.add_argument("--integrator", default="wavefront", choices=["megakernel", "wavefront", "stream"])
     ap.add_argument("--env-res", type=int, default=2048)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,7 +156,8 @@ def main():
     inst_all = instrumented(args.max_depth)
     inst_first = instrumented(1)
     rr.instrument, rr.max_depth = False, args.max_depth
-    rr.integrator = R.INTEGRATOR_WAVEFRONT if args.integrator == "wavefront" else R.INTEGRATOR_MEGAKERNEL
+    rr.integrator = {"megakernel": R.INTEGRATOR_MEGAKERNEL, "wavefront": R.INTEGRATOR_WAVEFRONT,
+                     "stream": R.INTEGRATOR_STREAM}[args.integrator]
     R.reset_render(rr)
 
     for k in range(args.warmup):

@@ -149,6 +149,7 @@ typedef struct ptc_hit
 
 #define PTC_INTEGRATOR_MEGAKERNEL 0u /* one lane walks one pixel's paths */
 #define PTC_INTEGRATOR_WAVEFRONT 1u  /* ray queues, compaction between bounces */
+#define PTC_INTEGRATOR_STREAM 2u     /* one persistent launch; idle lanes start new camera paths */
 
 #define PTC_ACCUM_RUNNING_MEAN 0u /* reference semantics (shader.rgen:202-216) */
 #define PTC_ACCUM_SUM 1u          /* un-normalised sum, for sharding samples */

@@ -682,7 +682,7 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
         set_error("ptc_render: samples_per_frame and n_frames must be >= 1");
         return PTC_E_INVALID;
     }
-    if (params->integrator > PTC_INTEGRATOR_WAVEFRONT || params->accumulate > PTC_ACCUM_SUM)
+    if (params->integrator > PTC_INTEGRATOR_STREAM || params->accumulate > PTC_ACCUM_SUM)
     {
         set_error("ptc_render: unknown integrator or accumulation mode");
         return PTC_E_INVALID;
@@ -721,9 +721,9 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
     hipEvent_t ev1 = timed ? ctx->ev_pool[ctx->ev_used].second : ctx->ev_stop;
     PTC_HIP_CHECK(hipEventRecord(ev0, ctx->stream));
     int rc;
-    if (params->integrator == PTC_INTEGRATOR_WAVEFRONT)
+    if (params->integrator != PTC_INTEGRATOR_MEGAKERNEL)
     {
-        rc = launch_render_wavefront(ctx, scene, film, F);
+        rc = launch_render_wavefront(ctx, scene, film, F, params->integrator == PTC_INTEGRATOR_STREAM);
     }
     else
     {

@@ -512,8 +512,33 @@ PTC_DEV uint32_t next_child(uint2 &ng, uint32_t octinv)
 PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t node_idx, uint2 &ng,
                        uint2 &tg)
 {
-    const uint4 *__restrict__ N = S.nodes + 5u * (size_t)node_idx;
-    const uint4 w0 = N[0], w1 = N[1], w2 = N[2], w3 = N[3], w4 = N[4];
+    // When every active lane of the wave visits the same node (the root always;
+    // whole tiles of camera rays often), fetch it once through the scalar cache
+    // instead of 64 times through the vector memory path.
+    uint4 w0, w1, w2, w3, w4;
+    const uint32_t first_idx = __builtin_amdgcn_readfirstlane(node_idx);
+    if (__builtin_amdgcn_ballot_w64(node_idx != first_idx) == 0ull)
+    {
+        // constant address space + wave-uniform address = scalar (SMEM) loads
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) u32x4 *scalar_ptr;
+        const scalar_ptr N = (scalar_ptr)(uintptr_t)(S.nodes + 5u * (size_t)first_idx);
+        const u32x4 s0 = N[0], s1 = N[1], s2 = N[2], s3 = N[3], s4 = N[4];
+        w0 = make_uint4(s0.x, s0.y, s0.z, s0.w);
+        w1 = make_uint4(s1.x, s1.y, s1.z, s1.w);
+        w2 = make_uint4(s2.x, s2.y, s2.z, s2.w);
+        w3 = make_uint4(s3.x, s3.y, s3.z, s3.w);
+        w4 = make_uint4(s4.x, s4.y, s4.z, s4.w);
+    }
+    else
+    {
+        const uint4 *__restrict__ N = S.nodes + 5u * (size_t)node_idx;
+        w0 = N[0];
+        w1 = N[1];
+        w2 = N[2];
+        w3 = N[3];
+        w4 = N[4];
+    }
     const uint32_t imask = w0.w >> 24;
     const uint32_t octinv = R.octinv;
     const bool negx = !(octinv & 1u), negy = !(octinv & 2u), negz = !(octinv & 4u);
@@ -538,35 +563,55 @@ PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t 
     const uint32_t fy0 = negy ? w2.z : w4.x, fy1 = negy ? w2.w : w4.y;
     const uint32_t nz0 = negz ? w4.z : w3.x, nz1 = negz ? w4.w : w3.y;
     const uint32_t fz0 = negz ? w3.x : w4.z, fz1 = negz ? w3.y : w4.w;
+    // Per slot, the bits a hit contributes: (meta >> 5) << (meta & 31), where an
+    // internal slot's index 24 + s is first XORed with octinv. Done on four
+    // packed meta bytes at a time: internal slots are the ones with bits 4 and 3
+    // of meta both set (leaf triangle offsets stay below 24).
+    const uint32_t oct4 = octinv * 0x01010101u;
+    uint32_t bits_of[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+    {
+        const uint32_t meta4 = half == 0 ? w1.z : w1.w;
+        const uint32_t inner4 = ((meta4 & (meta4 << 1)) & 0x10101010u) >> 4; // 1 per internal byte
+        const uint32_t index4 = (meta4 ^ (oct4 & (inner4 * 0xffu))) & 0x1f1f1f1fu;
+        const uint32_t count4 = (meta4 >> 5) & 0x07070707u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            bits_of[4 * half + k] = ((count4 >> (8 * k)) & 0xffu) << ((index4 >> (8 * k)) & 0xffu);
+        }
+    }
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz};
+    const f2 bnx2 = {bnx, bnx}, bny2 = {bny, bny}, bnz2 = {bnz, bnz};
+    const f2 bfx2 = {bfx, bfx}, bfy2 = {bfy, bfy}, bfz2 = {bfz, bfz};
     uint32_t hitmask = 0u;
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < 8; c += 2)
     {
-        const uint32_t meta = ((c < 4 ? w1.z : w1.w) >> (8 * (c & 3))) & 0xffu;
-        const float qnx = ubyte_f(c < 4 ? nx0 : nx1, c & 3);
-        const float qny = ubyte_f(c < 4 ? ny0 : ny1, c & 3);
-        const float qnz = ubyte_f(c < 4 ? nz0 : nz1, c & 3);
-        const float qfx = ubyte_f(c < 4 ? fx0 : fx1, c & 3);
-        const float qfy = ubyte_f(c < 4 ? fy0 : fy1, c & 3);
-        const float qfz = ubyte_f(c < 4 ? fz0 : fz1, c & 3);
-        // (slab distances are finite for finite input, so the hardware min / max
-        // and the compare-select forms agree)
-        float tn = __builtin_fmaxf(0.0f, __builtin_fmaf(qnx, sx, bnx));
-        tn = __builtin_fmaxf(tn, __builtin_fmaf(qny, sy, bny));
-        tn = __builtin_fmaxf(tn, __builtin_fmaf(qnz, sz, bnz));
-        float tf = __builtin_fminf(tlim, __builtin_fmaf(qfx, sx, bfx));
-        tf = __builtin_fminf(tf, __builtin_fmaf(qfy, sy, bfy));
-        tf = __builtin_fminf(tf, __builtin_fmaf(qfz, sz, bfz));
-        if (meta != 0u && tn <= tf)
+        // two slots at a time so the six plane distances use packed fma
+        const int k = c & 3;
+        const f2 qnx = {ubyte_f(c < 4 ? nx0 : nx1, k), ubyte_f(c < 4 ? nx0 : nx1, k + 1)};
+        const f2 qny = {ubyte_f(c < 4 ? ny0 : ny1, k), ubyte_f(c < 4 ? ny0 : ny1, k + 1)};
+        const f2 qnz = {ubyte_f(c < 4 ? nz0 : nz1, k), ubyte_f(c < 4 ? nz0 : nz1, k + 1)};
+        const f2 qfx = {ubyte_f(c < 4 ? fx0 : fx1, k), ubyte_f(c < 4 ? fx0 : fx1, k + 1)};
+        const f2 qfy = {ubyte_f(c < 4 ? fy0 : fy1, k), ubyte_f(c < 4 ? fy0 : fy1, k + 1)};
+        const f2 qfz = {ubyte_f(c < 4 ? fz0 : fz1, k), ubyte_f(c < 4 ? fz0 : fz1, k + 1)};
+        const f2 tnx = __builtin_elementwise_fma(qnx, sx2, bnx2);
+        const f2 tny = __builtin_elementwise_fma(qny, sy2, bny2);
+        const f2 tnz = __builtin_elementwise_fma(qnz, sz2, bnz2);
+        const f2 tfx = __builtin_elementwise_fma(qfx, sx2, bfx2);
+        const f2 tfy = __builtin_elementwise_fma(qfy, sy2, bfy2);
+        const f2 tfz = __builtin_elementwise_fma(qfz, sz2, bfz2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
         {
-            if ((imask >> c) & 1u)
-            {
-                hitmask |= 1u << (24u + ((uint32_t)c ^ octinv));
-            }
-            else
-            {
-                hitmask |= (meta >> 5) << (meta & 31u);
-            }
+            // (slab distances are finite for finite input, so the hardware
+            // min / max and the compare-select forms agree)
+            const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx[j], tny[j]), __builtin_fmaxf(tnz[j], 0.0f));
+            const float tf = __builtin_fminf(__builtin_fminf(tfx[j], tfy[j]), __builtin_fminf(tfz[j], tlim));
+            hitmask |= tn <= tf ? bits_of[c + j] : 0u;
         }
     }
     ng.x = w1.x;

@@ -131,7 +131,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
 int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &frame,
                        bool count);
 int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
-                            const DFrame &frame);
+                            const DFrame &frame, bool stream);
 int launch_primary_hits(ptc_context *ctx, const ptc_scene *scene, const DFrame &frame,
                         uint32_t *d_ids);
 int launch_trace(ptc_context *ctx, const ptc_scene *scene, const float *d_rays, size_t n,

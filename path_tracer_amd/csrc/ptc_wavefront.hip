@@ -242,14 +242,25 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
 // which keeps the lanes of a wave busy until the queue is empty. Every wave
 // leaves the loop once the queue is exhausted and its own lanes are done.
 constexpr int kDrainLds = 16; // LDS stack entries per lane in the drain kernel (two pushes per level)
+// kCamera = false: work items are the live paths of queue B.q[src] (n read from
+// B.counts[bounce0]). kCamera = true: work items are (pixel, dispatch) pairs,
+// n_items of them, generated in place as camera rays: item i covers lane
+// i % 64 of 8x8 pixel tile (i / 64) / n_disp for dispatch (i / 64) % n_disp, so
+// a wave that pulls 64 items at once gets one coherent tile; the
+// samples_per_frame samples of an item run back to back in the same lane on
+// one RNG stream, as shader.rgen:179 does.
+template <bool kCamera>
 __global__ void __launch_bounds__(kBlock, 5)
-k_wf_drain(DScene S, WfBuffers B, uint32_t bounce0, uint32_t max_depth, float tmax, int src,
-           uint32_t *__restrict__ head, DeviceStats *__restrict__ stats)
+k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t n_items, uint32_t n_disp,
+           uint32_t k_first, uint32_t *__restrict__ head, DeviceStats *__restrict__ stats)
 {
     __shared__ uint2 s_stack[kDrainLds * kBlock];
     const WfState qi = B.q[src];
-    const uint32_t n = B.counts[bounce0];
+    const uint32_t max_depth = F.max_depth;
+    const float tmax = F.tmax;
+    const uint32_t n = kCamera ? n_items : B.counts[bounce0];
     const uint32_t lane = lane_id();
+    uint32_t px = 0, py = 0, sample = 0; // kCamera: the item's pixel and current sample
     // Lane state machine. A lane is idle (kIdle), walking the tree for its
     // path's current ray (kTrav), or has its closest hit and waits to be shaded
     // (kShade). Every loop iteration runs at most one node visit per lane, so
@@ -285,7 +296,28 @@ k_wf_drain(DScene S, WfBuffers B, uint32_t bounce0, uint32_t max_depth, float tm
             }
             base = __shfl(base, (int)leader, 64);
             const uint32_t i = base + (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
-            if (mode == kIdle && i < n)
+            bool got = mode == kIdle && i < n;
+            if (got && kCamera)
+            {
+                const uint32_t tile_k = i >> 6, l = i & 63u;
+                const uint32_t tile = tile_k / n_disp, k = tile_k % n_disp;
+                const uint32_t tiles_x = (F.width + 7u) >> 3;
+                px = (tile % tiles_x) * 8u + (l & 7u);
+                py = (tile / tiles_x) * 8u + (l >> 3);
+                got = px < F.width && py < F.height;
+                if (got)
+                {
+                    const uint32_t pixel_index = py * F.width + px;
+                    sample = 0u;
+                    pid = (k * B.spf) * B.n_pixels + pixel_index;
+                    P.rng = seed_(pixel_index, F.global_frame_count + (k_first + k) * F.frame_stride);
+                    camera_ray(F, px, py, P.rng, P.origin, P.dir);
+                    T = v3(1.0f, 1.0f, 1.0f);
+                    L = v3(0.0f, 0.0f, 0.0f);
+                    bounce = 0u;
+                }
+            }
+            else if (got)
             {
                 const float4 a = qi.a[i], b = qi.b[i], c = qi.c[i];
                 const float2 d = qi.d[i];
@@ -296,6 +328,9 @@ k_wf_drain(DScene S, WfBuffers B, uint32_t bounce0, uint32_t max_depth, float tm
                 T = v3(c.x, c.y, c.z);
                 L = v3(c.w, d.x, d.y);
                 bounce = bounce0;
+            }
+            if (got)
+            {
                 R = make_ray_ctx(P.origin, P.dir, tmax);
                 best = no_hit(tmax);
                 ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
@@ -324,6 +359,30 @@ k_wf_drain(DScene S, WfBuffers B, uint32_t bounce0, uint32_t max_depth, float tm
                     sp = 0;
                     mode = kTrav;
                     ++rays;
+                }
+                else if (kCamera)
+                {
+                    B.radiance[pid] = make_float4(L.x, L.y, L.z, 1.0f);
+                    if (++sample < B.spf)
+                    {
+                        // next sample of the same dispatch continues the RNG stream
+                        pid += B.n_pixels;
+                        camera_ray(F, px, py, P.rng, P.origin, P.dir);
+                        T = v3(1.0f, 1.0f, 1.0f);
+                        L = v3(0.0f, 0.0f, 0.0f);
+                        bounce = 0u;
+                        R = make_ray_ctx(P.origin, P.dir, tmax);
+                        best = no_hit(tmax);
+                        ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
+                        tg = make_uint2(0u, 0u);
+                        sp = 0;
+                        mode = kTrav;
+                        ++rays;
+                    }
+                    else
+                    {
+                        mode = kIdle;
+                    }
                 }
                 else
                 {
@@ -460,7 +519,8 @@ size_t align256(size_t x)
 // flight at once. The samples of one dispatch share an RNG stream, so they run
 // as successive passes, each pass starting from the state the previous sample
 // of the same pixel ended with.
-int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &F0)
+int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &F0,
+                            bool stream)
 {
     hipStream_t st = ctx->stream;
     const uint32_t n_pixels = F0.width * F0.height;
@@ -471,8 +531,10 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
         1u, std::min<uint32_t>(F0.n_frames, (1u << 27) / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
     const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
     const size_t n_counts = (size_t)F0.max_depth + 2;
-    const size_t bytes = 2 * (align256(cap * 16) * 3 + align256(cap * 8)) + align256(cap * 16) + align256(cap * 8) +
-                         align256(cap * spf * 16) + align256(n_counts * 4) + align256(cap * 4);
+    // stream mode keeps live paths in registers: only the radiance array is needed
+    const size_t qcap = stream ? 1 : cap;
+    const size_t bytes = 2 * (align256(qcap * 16) * 3 + align256(qcap * 8)) + align256(qcap * 16) + align256(qcap * 8) +
+                         align256(cap * spf * 16) + align256(n_counts * 4) + align256(qcap * 4);
     if (bytes > ctx->wf_bytes)
     {
         PTC_HIP_CHECK(hipStreamSynchronize(st));
@@ -491,17 +553,17 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     WfBuffers B;
     for (int k = 0; k < 2; ++k)
     {
-        B.q[k].a = reinterpret_cast<float4 *>(take(cap * 16));
-        B.q[k].b = reinterpret_cast<float4 *>(take(cap * 16));
-        B.q[k].c = reinterpret_cast<float4 *>(take(cap * 16));
-        B.q[k].d = reinterpret_cast<float2 *>(take(cap * 8));
+        B.q[k].a = reinterpret_cast<float4 *>(take(qcap * 16));
+        B.q[k].b = reinterpret_cast<float4 *>(take(qcap * 16));
+        B.q[k].c = reinterpret_cast<float4 *>(take(qcap * 16));
+        B.q[k].d = reinterpret_cast<float2 *>(take(qcap * 8));
     }
-    B.hit = reinterpret_cast<float4 *>(take(cap * 16));
-    B.hit_ids = reinterpret_cast<uint2 *>(take(cap * 8));
+    B.hit = reinterpret_cast<float4 *>(take(qcap * 16));
+    B.hit_ids = reinterpret_cast<uint2 *>(take(qcap * 8));
     B.radiance = reinterpret_cast<float4 *>(take(cap * spf * 16));
     B.counts = reinterpret_cast<uint32_t *>(take(n_counts * 4));
-    uint32_t *carry = reinterpret_cast<uint32_t *>(take(cap * 4));
-    B.carry = spf > 1u ? carry : nullptr;
+    uint32_t *carry = reinterpret_cast<uint32_t *>(take(qcap * 4));
+    B.carry = spf > 1u && !stream ? carry : nullptr;
     B.spf = spf;
     B.n_pixels = n_pixels;
 
@@ -512,7 +574,21 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     {
         const uint32_t nb = std::min(max_batch, F0.n_frames - k0);
         const uint32_t n_paths = n_pixels * nb;
-        for (uint32_t s = 0; s < spf; ++s)
+        if (stream)
+        {
+            // one persistent launch: camera rays are generated as lanes fall idle
+            const uint32_t tiles8 = ((F0.width + 7u) >> 3) * ((F0.height + 7u) >> 3);
+            const uint32_t n_items = tiles8 * 64u * nb;
+            PTC_HIP_CHECK(hipMemsetAsync(B.counts, 0, n_counts * 4, st));
+            {
+                PhaseTimer timer(ctx, PTC_PHASE_DRAIN);
+                const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_items + kBlock - 1) / kBlock);
+                k_wf_drain<true><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, 0u, 0, n_items, nb, k0,
+                                                           B.counts + (F0.max_depth + 1u), ctx->d_stats);
+            }
+            k_wf_stats<<<1, 64, 0, st>>>(B.counts, n_paths * spf, 0u, 1u, ctx->d_stats);
+        }
+        for (uint32_t s = 0; s < (stream ? 0u : spf); ++s)
         {
             PTC_HIP_CHECK(hipMemsetAsync(B.counts, 0, n_counts * 4, st));
             {
@@ -533,8 +609,8 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             if (drain_b < F0.max_depth)
             {
                 PhaseTimer timer(ctx, PTC_PHASE_DRAIN);
-                k_wf_drain<<<blocks, kBlock, 0, st>>>(scene->d, B, drain_b, F0.max_depth, F0.tmax, (int)(drain_b & 1u),
-                                                     B.counts + (F0.max_depth + 1u), ctx->d_stats);
+                k_wf_drain<false><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, drain_b, (int)(drain_b & 1u), 0u, 0u, 0u,
+                                                            B.counts + (F0.max_depth + 1u), ctx->d_stats);
             }
             k_wf_stats<<<1, 64, 0, st>>>(B.counts, n_paths, F0.max_depth, drain_b, ctx->d_stats);
         }

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libptcore.so")
 
 KIND_DIFFUSE, KIND_SPECULAR, KIND_EMISSIVE, KIND_DIELECTRIC = 0, 1, 2, 3
-INTEGRATOR_MEGAKERNEL, INTEGRATOR_WAVEFRONT = 0, 1
+INTEGRATOR_MEGAKERNEL, INTEGRATOR_WAVEFRONT, INTEGRATOR_STREAM = 0, 1, 2
 ACCUM_RUNNING_MEAN, ACCUM_SUM = 0, 1
 NO_HIT = 0xFFFFFFFF
 

@@ -102,8 +102,8 @@ def test_primary_hit_ids(scene_pair, oracle):
         assert np.array_equal(ids, ref), f"{name}: {np.count_nonzero(ids != ref)} primary ids differ"
 
 
-@pytest.mark.parametrize("integrator", [R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT],
-                         ids=["megakernel", "wavefront"])
+@pytest.mark.parametrize("integrator", [R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM],
+                         ids=["megakernel", "wavefront", "stream"])
 @pytest.mark.parametrize("spf,n_frames", [(1, 3), (2, 2)])
 def test_render_bit_exact(scene_pair, ctx, oracle, spf, n_frames, integrator):
     name, sc, dev, orc = scene_pair
@@ -134,7 +134,7 @@ def test_ray_and_path_counters(ctx, oracle):
     cam = R.default_camera(w, h)
     rr = R.RenderResources(ctx, w, h, dev)
     _, _, ref = orc.render(oracle.make_push(cam.as_dict()), w, h, n_frames=2, use_bvh=False)
-    for integrator in (R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT):
+    for integrator in (R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM):
         rr.integrator = integrator
         R.reset_render(rr)
         ctx.reset_stats()
