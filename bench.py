@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-png", default="")
     ap.add_argument("--wavefront-bounces", type=int, default=0)
+    ap.add_argument("--search-radius", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -121,7 +122,8 @@ def main():
     # the film's accumulator lives in a torch tensor so RCCL can reduce it in place
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     torch.cuda.synchronize()
-    rr = R.create_render_resources(ctx, W, H, scene, accum_dev=accum.data_ptr())
+    rr = R.create_render_resources(ctx, W, H, scene, accum_dev=accum.data_ptr(),
+                                   search_radius=args.search_radius)
     rr.max_depth = args.max_depth
     rr.accumulate = R.ACCUM_SUM
     rr.integrator = R.INTEGRATOR_WAVEFRONT if args.integrator == "wavefront" else R.INTEGRATOR_MEGAKERNEL
