@@ -507,38 +507,12 @@ PTC_DEV uint32_t next_child(uint2 &ng, uint32_t octinv)
     return ng.x + (uint32_t)__builtin_popcount(ng.y & 0xffu & ((1u << slot) - 1u));
 }
 
-// Loads one wide node and tests its 8 child boxes against the ray; yields the
-// group of hit internal children and the group of triangles of hit leaf slots.
-PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t node_idx, uint2 &ng,
-                       uint2 &tg)
+// Tests the 8 child boxes of one wide node (its five 16-byte words w0..w4)
+// against the ray; yields the group of hit internal children and the group of
+// triangles of hit leaf slots.
+PTC_DEV void node_eval(const uint4 w0, const uint4 w1, const uint4 w2, const uint4 w3, const uint4 w4,
+                       const RayCtx &R, float best_t, uint2 &ng, uint2 &tg)
 {
-    // When every active lane of the wave visits the same node (the root always;
-    // whole tiles of camera rays often), fetch it once through the scalar cache
-    // instead of 64 times through the vector memory path.
-    uint4 w0, w1, w2, w3, w4;
-    const uint32_t first_idx = __builtin_amdgcn_readfirstlane(node_idx);
-    if (__builtin_amdgcn_ballot_w64(node_idx != first_idx) == 0ull)
-    {
-        // constant address space + wave-uniform address = scalar (SMEM) loads
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(4))) u32x4 *scalar_ptr;
-        const scalar_ptr N = (scalar_ptr)(uintptr_t)(S.nodes + 5u * (size_t)first_idx);
-        const u32x4 s0 = N[0], s1 = N[1], s2 = N[2], s3 = N[3], s4 = N[4];
-        w0 = make_uint4(s0.x, s0.y, s0.z, s0.w);
-        w1 = make_uint4(s1.x, s1.y, s1.z, s1.w);
-        w2 = make_uint4(s2.x, s2.y, s2.z, s2.w);
-        w3 = make_uint4(s3.x, s3.y, s3.z, s3.w);
-        w4 = make_uint4(s4.x, s4.y, s4.z, s4.w);
-    }
-    else
-    {
-        const uint4 *__restrict__ N = S.nodes + 5u * (size_t)node_idx;
-        w0 = N[0];
-        w1 = N[1];
-        w2 = N[2];
-        w3 = N[3];
-        w4 = N[4];
-    }
     const uint32_t imask = w0.w >> 24;
     const uint32_t octinv = R.octinv;
     const bool negx = !(octinv & 1u), negy = !(octinv & 2u), negz = !(octinv & 4u);
@@ -620,11 +594,44 @@ PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t 
     tg.y = hitmask & ~kNodeBits;
 }
 
-// Tests one triangle and keeps it if it beats the best hit in (t, flat) order.
-PTC_DEV void tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index, Hit &best)
+// Loads one wide node and tests it.
+PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t node_idx, uint2 &ng,
+                       uint2 &tg)
 {
-    const float4 *__restrict__ T = S.tris + 3u * (size_t)tri_index;
-    const float4 a = T[0], b = T[1], c = T[2];
+    // When every active lane of the wave visits the same node (the root always;
+    // whole tiles of camera rays often), fetch it once through the scalar cache
+    // instead of 64 times through the vector memory path.
+    uint4 w0, w1, w2, w3, w4;
+    const uint32_t first_idx = __builtin_amdgcn_readfirstlane(node_idx);
+    if (__builtin_amdgcn_ballot_w64(node_idx != first_idx) == 0ull)
+    {
+        // constant address space + wave-uniform address = scalar (SMEM) loads
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) u32x4 *scalar_ptr;
+        const scalar_ptr N = (scalar_ptr)(uintptr_t)(S.nodes + 5u * (size_t)first_idx);
+        const u32x4 s0 = N[0], s1 = N[1], s2 = N[2], s3 = N[3], s4 = N[4];
+        w0 = make_uint4(s0.x, s0.y, s0.z, s0.w);
+        w1 = make_uint4(s1.x, s1.y, s1.z, s1.w);
+        w2 = make_uint4(s2.x, s2.y, s2.z, s2.w);
+        w3 = make_uint4(s3.x, s3.y, s3.z, s3.w);
+        w4 = make_uint4(s4.x, s4.y, s4.z, s4.w);
+    }
+    else
+    {
+        const uint4 *__restrict__ N = S.nodes + 5u * (size_t)node_idx;
+        w0 = N[0];
+        w1 = N[1];
+        w2 = N[2];
+        w3 = N[3];
+        w4 = N[4];
+    }
+    node_eval(w0, w1, w2, w3, w4, R, best_t, ng, tg);
+}
+
+// Tests one triangle (its three 16-byte words) and keeps it if it beats the
+// best hit in (t, flat) order.
+PTC_DEV void tri_eval(const float4 a, const float4 b, const float4 c, const RayCtx &R, Hit &best)
+{
     float t, u, v;
     if (mt_test(R.o, R.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), R.tmax, t, u, v))
     {
@@ -639,6 +646,12 @@ PTC_DEV void tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index, Hit 
             best.primitive = __float_as_uint(b.w);
         }
     }
+}
+
+PTC_DEV void tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index, Hit &best)
+{
+    const float4 *__restrict__ T = S.tris + 3u * (size_t)tri_index;
+    tri_eval(T[0], T[1], T[2], R, best);
 }
 
 // Traversal stack: the first kLdsStack entries of a lane live in LDS (entry e

@@ -134,16 +134,25 @@ PTC_DEV void store_state(const WfState &q, uint32_t slot, const Payload &P, uint
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample)
+k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample,
+             uint32_t n_disp)
 {
     __shared__ uint2 s_stack[kLdsStack * kBlock];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tiles_x = (F.width + 15u) >> 4;
-    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    // consecutive blocks are the dispatches of one tile, so the blocks resident
+    // at any time (and the queue they fill) stay within a few tiles' geometry
+    // and those tiles form a compact patch: tiles are numbered along a Z-order
+    // curve inside 8x8-tile groups.
+    const uint32_t tile = blockIdx.x / n_disp;
+    const uint32_t k = blockIdx.x % n_disp; // dispatch within this batch
+    const uint32_t groups_x = (tiles_x + 7u) >> 3;
+    const uint32_t group = tile >> 6, m = tile & 63u;
+    const uint32_t bx = (group % groups_x) * 8u + ((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u));
+    const uint32_t by = (group / groups_x) * 8u + (((m >> 1) & 1u) | ((m >> 2) & 2u) | ((m >> 3) & 4u));
     const uint32_t px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const uint32_t k = blockIdx.y; // dispatch within this batch
-    const bool inside = px < F.width && py < F.height;
+    const bool inside = px < F.width && py < F.height; // false for all lanes of tiles past the edge
     bool alive = false;
     Payload P;
     vec3 T = v3(1.0f, 1.0f, 1.0f), L = v3(0.0f, 0.0f, 0.0f);
@@ -567,7 +576,8 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     B.spf = spf;
     B.n_pixels = n_pixels;
 
-    const uint32_t tiles = ((F0.width + 15u) >> 4) * ((F0.height + 15u) >> 4);
+    // primary-pass tiles: whole 8x8 groups of 16x16-pixel tiles
+    const uint32_t tiles = ((F0.width + 127u) >> 7) * ((F0.height + 127u) >> 7) * 64u;
     const uint32_t persistent_blocks = (uint32_t)ctx->n_cus * 6u;
     uint32_t sample_count = F0.sample_count;
     for (uint32_t k0 = 0; k0 < F0.n_frames; k0 += max_batch)
@@ -593,7 +603,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             PTC_HIP_CHECK(hipMemsetAsync(B.counts, 0, n_counts * 4, st));
             {
                 PhaseTimer timer(ctx, PTC_PHASE_PRIMARY);
-                k_wf_primary<<<dim3(tiles, nb), kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0, s);
+                k_wf_primary<<<tiles * nb, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0, s, nb);
             }
             const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_paths + kBlock - 1) / kBlock);
             // bounces [1, drain_b) as trace / shade launch pairs over compacted queues
