@@ -179,7 +179,9 @@ PTC_DEV vec3 reflect_diffuse(vec3 normal, uint32_t &rng)
     return normalize(normal + sample_sphere(rng));
 }
 
-// Ray_payload of shader_common.glsl:4-13
+// Ray_payload of shader_common.glsl:4-13. Material and miss programs build one
+// and return it by value; every field is assigned exactly once on every path,
+// which keeps the whole payload in registers.
 struct Payload
 {
     vec3 color;
@@ -193,34 +195,35 @@ struct Payload
 
 // diffuse.rchit:5-14, specular.rchit:5-14, emissive.rchit:5-14,
 // dielectric.rchit:5-52, after get_hit() produced pos / nrm.
-PTC_DEV void material_scatter(uint32_t kind, vec3 dir, vec3 pos, vec3 nrm, Payload &P)
+PTC_DEV Payload material_scatter(uint32_t kind, vec3 dir, vec3 pos, vec3 nrm, uint32_t rng)
 {
-    P.hit_sky = false;
+    vec3 origin, out_dir, color, emissivity;
+    float attenuation = 1.0f;
     if (kind == 0u)
     {
-        P.origin = offset_position_along_normal(pos, nrm);
-        P.dir = reflect_diffuse(nrm, P.rng);
-        P.color = v3((nrm.x + 1.0f) * 0.5f, (nrm.y + 1.0f) * 0.5f, (nrm.z + 1.0f) * 0.5f);
-        P.emissivity = v3(0.0f, 0.0f, 0.0f);
+        origin = offset_position_along_normal(pos, nrm);
+        out_dir = reflect_diffuse(nrm, rng);
+        color = v3((nrm.x + 1.0f) * 0.5f, (nrm.y + 1.0f) * 0.5f, (nrm.z + 1.0f) * 0.5f);
+        emissivity = v3(0.0f, 0.0f, 0.0f);
     }
     else if (kind == 1u)
     {
-        P.origin = offset_position_along_normal(pos, nrm);
-        P.dir = reflect(dir, nrm);
-        P.color = v3(0.75f, 0.75f, 0.75f);
-        P.emissivity = v3(0.0f, 0.0f, 0.0f);
+        origin = offset_position_along_normal(pos, nrm);
+        out_dir = reflect(dir, nrm);
+        color = v3(0.75f, 0.75f, 0.75f);
+        emissivity = v3(0.0f, 0.0f, 0.0f);
     }
     else if (kind == 2u)
     {
-        P.origin = offset_position_along_normal(pos, nrm);
-        P.dir = reflect_diffuse(nrm, P.rng);
-        P.color = v3(0.75f, 0.75f, 0.75f);
-        P.emissivity = v3(5.0f, 5.0f, 5.0f);
+        origin = offset_position_along_normal(pos, nrm);
+        out_dir = reflect_diffuse(nrm, rng);
+        color = v3(0.75f, 0.75f, 0.75f);
+        emissivity = v3(5.0f, 5.0f, 5.0f);
     }
     else
     {
-        P.color = v3(1.0f, 1.0f, 1.0f);
-        P.emissivity = v3(0.0f, 0.0f, 0.0f);
+        color = v3(1.0f, 1.0f, 1.0f);
+        emissivity = v3(0.0f, 0.0f, 0.0f);
         const bool into = dot(dir, nrm) < 0.0f;
         const vec3 normal = into ? nrm : -nrm;
         const vec3 reflected_dir = reflect(dir, normal);
@@ -231,34 +234,37 @@ PTC_DEV void material_scatter(uint32_t kind, vec3 dir, vec3 pos, vec3 nrm, Paylo
         const float cos2t = 1.0f - n_ratio * n_ratio * (1.0f - ddn * ddn);
         if (cos2t < 0.0f)
         {
-            P.origin = offset_position_along_normal(pos, normal);
-            P.dir = reflected_dir;
-            return;
-        }
-        const float k = (into ? 1.0f : -1.0f) * (ddn * n_ratio + __builtin_sqrtf(cos2t));
-        const vec3 transmitted_dir = normalize(dir * n_ratio - nrm * k);
-        const float a = n_glass - n_air;
-        const float b = n_glass + n_air;
-        const float R0 = a * a / (b * b);
-        const float c = 1.0f - (into ? -ddn : dot(transmitted_dir, nrm));
-        const float Re = R0 + (1.0f - R0) * c * c * c * c * c;
-        const float Tr = 1.0f - Re;
-        const float Pr = 0.25f + 0.5f * Re;
-        const float RP = Re / Pr;
-        const float TP = Tr / (1.0f - Pr);
-        if (random_(P.rng) < Pr)
-        {
-            P.attenuation = RP;
-            P.origin = offset_position_along_normal(pos, normal);
-            P.dir = reflected_dir;
+            origin = offset_position_along_normal(pos, normal);
+            out_dir = reflected_dir;
         }
         else
         {
-            P.attenuation = TP;
-            P.origin = offset_position_along_normal(pos, -normal);
-            P.dir = transmitted_dir;
+            const float k = (into ? 1.0f : -1.0f) * (ddn * n_ratio + __builtin_sqrtf(cos2t));
+            const vec3 transmitted_dir = normalize(dir * n_ratio - nrm * k);
+            const float a = n_glass - n_air;
+            const float b = n_glass + n_air;
+            const float R0 = a * a / (b * b);
+            const float c = 1.0f - (into ? -ddn : dot(transmitted_dir, nrm));
+            const float Re = R0 + (1.0f - R0) * c * c * c * c * c;
+            const float Tr = 1.0f - Re;
+            const float Pr = 0.25f + 0.5f * Re;
+            const float RP = Re / Pr;
+            const float TP = Tr / (1.0f - Pr);
+            const bool reflects = random_(rng) < Pr;
+            attenuation = reflects ? RP : TP;
+            origin = offset_position_along_normal(pos, reflects ? normal : -normal);
+            out_dir = reflects ? reflected_dir : transmitted_dir;
         }
     }
+    Payload P;
+    P.color = color;
+    P.emissivity = emissivity;
+    P.origin = origin;
+    P.dir = out_dir;
+    P.attenuation = attenuation;
+    P.rng = rng;
+    P.hit_sky = false;
+    return P;
 }
 
 PTC_DEV vec3 load3(const float *__restrict__ p)
@@ -268,7 +274,7 @@ PTC_DEV vec3 load3(const float *__restrict__ p)
 
 // get_hit() of closest_hit_common.glsl:59-89 followed by the material program
 // selected by the instance's kind (the SBT record offset).
-PTC_DEV void closest_hit(const DScene &S, Payload &P, vec3 ray_dir, const Hit &h)
+PTC_DEV Payload closest_hit(const DScene &S, vec3 ray_dir, const Hit &h, uint32_t rng)
 {
     const DInstance *__restrict__ I = &S.instances[h.instance];
     const uint32_t *__restrict__ idx = S.indices + 3u * (size_t)(I->tri_offset + h.primitive);
@@ -287,7 +293,7 @@ PTC_DEV void closest_hit(const DScene &S, Payload &P, vec3 ray_dir, const Hit &h
     const vec3 world_normal = normalize(xform_normal_rowvec(I->w2o, object_normal));
     const vec3 world_position = xform_point(I->o2w, object_position);
     const vec3 nrm = faceforward(world_normal, ray_dir, world_normal);
-    material_scatter(I->kind, ray_dir, world_position, nrm, P);
+    return material_scatter(I->kind, ray_dir, world_position, nrm, rng);
 }
 
 // ---- miss program: shader.rmiss:11-29 ----------------------------------------
@@ -341,6 +347,63 @@ PTC_DEV vec3 miss_color(const DScene &S, vec3 d)
     const float u = (azimuth + kPi) / kTwoPi;
     const float v = inclination / kPi;
     return env_lookup(S, u, v);
+}
+
+// What the closest-hit or the miss program leaves in the payload for a ray
+// that went in direction ray_dir: shader.rgen:68-78 with shader.rmiss:25-27.
+PTC_DEV Payload bounce_payload(const DScene &S, const Hit &h, vec3 ray_origin, vec3 ray_dir, uint32_t rng)
+{
+    Payload P;
+    if (h.flat == kNoHit)
+    {
+        const vec3 c = miss_color(S, ray_dir);
+        P.color = c;
+        P.emissivity = c;
+        P.origin = ray_origin;
+        P.dir = ray_dir;
+        P.attenuation = 1.0f;
+        P.rng = rng;
+        P.hit_sky = true;
+    }
+    else
+    {
+        P = closest_hit(S, ray_dir, h, rng);
+    }
+    return P;
+}
+
+// A path between bounces, and the part of the path loop after the trace call,
+// shader.rgen:80-96: adds the emission, ends the path at the sky or by Russian
+// roulette, updates the throughput. Returns true when the path continues from
+// (origin, dir).
+struct PathState
+{
+    vec3 origin, dir;
+    vec3 throughput, radiance;
+    uint32_t rng;
+};
+
+PTC_DEV bool path_bounce(const DScene &S, const Hit &h, PathState &ps)
+{
+    const Payload P = bounce_payload(S, h, ps.origin, ps.dir, ps.rng);
+    uint32_t rng = P.rng;
+    const vec3 radiance = ps.radiance + ps.throughput * P.emissivity;
+    vec3 hit_color = P.color;
+    const float p = fmax_(hit_color.x, fmax_(hit_color.y, hit_color.z));
+    bool alive = !P.hit_sky;
+    vec3 throughput = ps.throughput;
+    if (alive)
+    {
+        alive = random_(rng) < p;
+        hit_color = hit_color / p;
+        throughput = throughput * (hit_color * P.attenuation);
+    }
+    ps.origin = P.origin;
+    ps.dir = P.dir;
+    ps.throughput = throughput;
+    ps.radiance = radiance;
+    ps.rng = rng;
+    return alive;
 }
 
 // ---- tone map + UNORM8: shader.rgen:141-162, :218-223 ------------------------
@@ -734,46 +797,26 @@ PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *ld
 // ---- path loop: shader.rgen:60-100 -------------------------------------------
 
 template <bool kCount>
-PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, Payload &P, uint2 *lds_stack,
+PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, vec3 origin, vec3 dir, uint32_t &rng_io, uint2 *lds_stack,
                       uint32_t stride, uint32_t &rays, TraceCounters *ctr)
 {
-    vec3 accumulated_color = v3(0.0f, 0.0f, 0.0f);
-    vec3 accumulated_reflectance = v3(1.0f, 1.0f, 1.0f);
+    PathState ps;
+    ps.origin = origin;
+    ps.dir = dir;
+    ps.throughput = v3(1.0f, 1.0f, 1.0f);
+    ps.radiance = v3(0.0f, 0.0f, 0.0f);
+    ps.rng = rng_io;
     for (uint32_t bounces = 0; bounces < f.max_depth; ++bounces)
     {
-        P.attenuation = 1.0f;
-        const vec3 ray_dir = P.dir;
-        const Hit h = trace_closest<kCount>(S, P.origin, ray_dir, f.tmax, lds_stack, stride, ctr);
+        const Hit h = trace_closest<kCount>(S, ps.origin, ps.dir, f.tmax, lds_stack, stride, ctr);
         ++rays;
-        if (h.flat == kNoHit)
+        if (!path_bounce(S, h, ps))
         {
-            const vec3 c = miss_color(S, ray_dir);
-            P.color = c;
-            P.emissivity = c;
-            P.hit_sky = true;
+            break;
         }
-        else
-        {
-            closest_hit(S, P, ray_dir, h);
-        }
-        accumulated_color = accumulated_color + accumulated_reflectance * P.emissivity;
-        if (P.hit_sky)
-        {
-            return accumulated_color;
-        }
-        vec3 hit_color = P.color;
-        const float p = fmax_(hit_color.x, fmax_(hit_color.y, hit_color.z));
-        if (random_(P.rng) < p)
-        {
-            hit_color = hit_color / p;
-        }
-        else
-        {
-            return accumulated_color;
-        }
-        accumulated_reflectance = accumulated_reflectance * (hit_color * P.attenuation);
     }
-    return accumulated_color;
+    rng_io = ps.rng;
+    return ps.radiance;
 }
 
 // running mean of shader.rgen:202-216 (or the plain sum used when samples are

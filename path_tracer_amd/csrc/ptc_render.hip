@@ -49,13 +49,13 @@ k_render_mega(DScene S, DFrame F, float4 *__restrict__ accum, uint32_t *__restri
         uint32_t frame = F.global_frame_count;
         for (uint32_t k = 0; k < F.n_frames; ++k)
         {
-            Payload P;
-            P.rng = seed_(pixel_index, frame);
+            uint32_t rng = seed_(pixel_index, frame);
             float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             for (uint32_t s = 0; s < F.samples_per_frame; ++s)
             {
-                camera_ray(F, px, py, P.rng, P.origin, P.dir);
-                const vec3 c = radiance<kCount>(S, F, P, stack, kBlock, rays, &ctr);
+                vec3 origin, dir;
+                camera_ray(F, px, py, rng, origin, dir);
+                const vec3 c = radiance<kCount>(S, F, origin, dir, rng, stack, kBlock, rays, &ctr);
                 ++paths;
                 acc.x += c.x;
                 acc.y += c.y;

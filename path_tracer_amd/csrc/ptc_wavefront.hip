@@ -89,48 +89,34 @@ PTC_DEV uint32_t queue_append(bool alive, uint32_t *counter)
     return base + rank;
 }
 
-// One bounce of radiance() after the closest-hit query: shader.rgen:80-96.
-// Returns true when the path continues.
-PTC_DEV bool shade_bounce(const DScene &S, const Hit &h, Payload &P, vec3 &T, vec3 &L)
+PTC_DEV void store_state(const WfState &q, uint32_t slot, const PathState &ps, uint32_t pid)
 {
-    const vec3 ray_dir = P.dir;
-    P.attenuation = 1.0f;
-    if (h.flat == kNoHit)
-    {
-        const vec3 c = miss_color(S, ray_dir);
-        P.color = c;
-        P.emissivity = c;
-        P.hit_sky = true;
-    }
-    else
-    {
-        closest_hit(S, P, ray_dir, h);
-    }
-    L = L + T * P.emissivity;
-    if (P.hit_sky)
-    {
-        return false;
-    }
-    vec3 hit_color = P.color;
-    const float p = fmax_(hit_color.x, fmax_(hit_color.y, hit_color.z));
-    if (random_(P.rng) < p)
-    {
-        hit_color = hit_color / p;
-    }
-    else
-    {
-        return false;
-    }
-    T = T * (hit_color * P.attenuation);
-    return true;
+    q.a[slot] = make_float4(ps.origin.x, ps.origin.y, ps.origin.z, __uint_as_float(ps.rng));
+    q.b[slot] = make_float4(ps.dir.x, ps.dir.y, ps.dir.z, __uint_as_float(pid));
+    q.c[slot] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, ps.radiance.x);
+    q.d[slot] = make_float2(ps.radiance.y, ps.radiance.z);
 }
 
-PTC_DEV void store_state(const WfState &q, uint32_t slot, const Payload &P, uint32_t pid, vec3 T, vec3 L)
+PTC_DEV uint32_t load_state(const WfState &q, uint32_t slot, PathState &ps)
 {
-    q.a[slot] = make_float4(P.origin.x, P.origin.y, P.origin.z, __uint_as_float(P.rng));
-    q.b[slot] = make_float4(P.dir.x, P.dir.y, P.dir.z, __uint_as_float(pid));
-    q.c[slot] = make_float4(T.x, T.y, T.z, L.x);
-    q.d[slot] = make_float2(L.y, L.z);
+    const float4 a = q.a[slot], b = q.b[slot], c = q.c[slot];
+    const float2 d = q.d[slot];
+    ps.origin = v3(a.x, a.y, a.z);
+    ps.rng = __float_as_uint(a.w);
+    ps.dir = v3(b.x, b.y, b.z);
+    ps.throughput = v3(c.x, c.y, c.z);
+    ps.radiance = v3(c.w, d.x, d.y);
+    return __float_as_uint(b.w); // path id
+}
+
+PTC_DEV PathState camera_path(const DFrame &F, uint32_t px, uint32_t py, uint32_t rng)
+{
+    PathState ps;
+    ps.rng = rng;
+    camera_ray(F, px, py, ps.rng, ps.origin, ps.dir);
+    ps.throughput = v3(1.0f, 1.0f, 1.0f);
+    ps.radiance = v3(0.0f, 0.0f, 0.0f);
+    return ps;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -154,32 +140,31 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
     const uint32_t py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
     const bool inside = px < F.width && py < F.height; // false for all lanes of tiles past the edge
     bool alive = false;
-    Payload P;
-    vec3 T = v3(1.0f, 1.0f, 1.0f), L = v3(0.0f, 0.0f, 0.0f);
+    PathState ps = camera_path(F, 0u, 0u, 0u);
     uint32_t pid = 0;
     if (inside)
     {
         const uint32_t pixel_index = py * F.width + px;
         const uint32_t n_pixels = F.width * F.height;
         pid = (k * B.spf + sample) * n_pixels + pixel_index;
-        P.rng = sample == 0u ? seed_(pixel_index, frame_first + (k_first + k) * F.frame_stride)
-                             : B.carry[k * n_pixels + pixel_index];
-        camera_ray(F, px, py, P.rng, P.origin, P.dir);
+        ps = camera_path(F, px, py,
+                         sample == 0u ? seed_(pixel_index, frame_first + (k_first + k) * F.frame_stride)
+                                      : B.carry[k * n_pixels + pixel_index]);
         alive = F.max_depth > 0u;
         if (alive)
         {
-            const Hit h = trace_closest<false>(S, P.origin, P.dir, F.tmax, s_stack + threadIdx.x, kBlock, nullptr);
-            alive = shade_bounce(S, h, P, T, L) && F.max_depth > 1u;
+            const Hit h = trace_closest<false>(S, ps.origin, ps.dir, F.tmax, s_stack + threadIdx.x, kBlock, nullptr);
+            alive = path_bounce(S, h, ps) && F.max_depth > 1u;
         }
         if (!alive)
         {
-            finish_path(B, pid, L, P.rng);
+            finish_path(B, pid, ps.radiance, ps.rng);
         }
     }
     const uint32_t slot = queue_append(alive, &B.counts[1]);
     if (alive)
     {
-        store_state(B.q[1], slot, P, pid, T, L);
+        store_state(B.q[1], slot, ps, pid);
     }
 }
 
@@ -208,21 +193,13 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock)
     {
         bool alive = false;
-        Payload P;
-        vec3 T = v3(0.0f, 0.0f, 0.0f), L = T;
+        PathState ps;
         uint32_t pid = 0;
         if (i < n)
         {
-            const float4 a = qi.a[i], b = qi.b[i], c = qi.c[i];
-            const float2 d = qi.d[i];
+            pid = load_state(qi, i, ps);
             const float4 hr = B.hit[i];
             const uint2 hid = B.hit_ids[i];
-            P.origin = v3(a.x, a.y, a.z);
-            P.rng = __float_as_uint(a.w);
-            P.dir = v3(b.x, b.y, b.z);
-            pid = __float_as_uint(b.w);
-            T = v3(c.x, c.y, c.z);
-            L = v3(c.w, d.x, d.y);
             Hit h;
             h.t = hr.x;
             h.u = hr.y;
@@ -230,16 +207,16 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
             h.flat = __float_as_uint(hr.w);
             h.instance = hid.x;
             h.primitive = hid.y;
-            alive = shade_bounce(S, h, P, T, L) && (bounce + 1u) < max_depth;
+            alive = path_bounce(S, h, ps) && (bounce + 1u) < max_depth;
             if (!alive)
             {
-                finish_path(B, pid, L, P.rng);
+                finish_path(B, pid, ps.radiance, ps.rng);
             }
         }
         const uint32_t slot = queue_append(alive, &B.counts[bounce + 1u]);
         if (alive)
         {
-            store_state(qo, slot, P, pid, T, L);
+            store_state(qo, slot, ps, pid);
         }
     }
 }
@@ -259,7 +236,7 @@ constexpr int kDrainLds = 16; // LDS stack entries per lane in the drain kernel 
 // samples_per_frame samples of an item run back to back in the same lane on
 // one RNG stream, as shader.rgen:179 does.
 template <bool kCamera>
-__global__ void __launch_bounds__(kBlock, 5)
+__global__ void __launch_bounds__(kBlock, 4)
 k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t n_items, uint32_t n_disp,
            uint32_t k_first, uint32_t *__restrict__ head, DeviceStats *__restrict__ stats)
 {
@@ -280,8 +257,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     constexpr uint32_t kFetchMin = 8u, kShadeMin = 16u; // lanes that must want a phase before it runs
     uint32_t mode = kIdle;
     bool exhausted = n == 0u;
-    Payload P;
-    vec3 T = v3(0.0f, 0.0f, 0.0f), L = T;
+    PathState ps = camera_path(F, 0u, 0u, 0u);
     uint32_t pid = 0, bounce = 0, rays = 0;
     RayCtx R = make_ray_ctx(v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f), tmax);
     Hit best = no_hit(tmax);
@@ -319,28 +295,19 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                     const uint32_t pixel_index = py * F.width + px;
                     sample = 0u;
                     pid = (k * B.spf) * B.n_pixels + pixel_index;
-                    P.rng = seed_(pixel_index, F.global_frame_count + (k_first + k) * F.frame_stride);
-                    camera_ray(F, px, py, P.rng, P.origin, P.dir);
-                    T = v3(1.0f, 1.0f, 1.0f);
-                    L = v3(0.0f, 0.0f, 0.0f);
+                    ps = camera_path(F, px, py,
+                                     seed_(pixel_index, F.global_frame_count + (k_first + k) * F.frame_stride));
                     bounce = 0u;
                 }
             }
             else if (got)
             {
-                const float4 a = qi.a[i], b = qi.b[i], c = qi.c[i];
-                const float2 d = qi.d[i];
-                P.origin = v3(a.x, a.y, a.z);
-                P.rng = __float_as_uint(a.w);
-                P.dir = v3(b.x, b.y, b.z);
-                pid = __float_as_uint(b.w);
-                T = v3(c.x, c.y, c.z);
-                L = v3(c.w, d.x, d.y);
+                pid = load_state(qi, i, ps);
                 bounce = bounce0;
             }
             if (got)
             {
-                R = make_ray_ctx(P.origin, P.dir, tmax);
+                R = make_ray_ctx(ps.origin, ps.dir, tmax);
                 best = no_hit(tmax);
                 ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
                 tg = make_uint2(0u, 0u);
@@ -357,11 +324,11 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
         {
             if (mode == kShade)
             {
-                const bool alive = shade_bounce(S, best, P, T, L) && (bounce + 1u) < max_depth;
+                const bool alive = path_bounce(S, best, ps) && (bounce + 1u) < max_depth;
                 ++bounce;
                 if (alive)
                 {
-                    R = make_ray_ctx(P.origin, P.dir, tmax);
+                    R = make_ray_ctx(ps.origin, ps.dir, tmax);
                     best = no_hit(tmax);
                     ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
                     tg = make_uint2(0u, 0u);
@@ -371,16 +338,14 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 }
                 else if (kCamera)
                 {
-                    B.radiance[pid] = make_float4(L.x, L.y, L.z, 1.0f);
+                    B.radiance[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, 1.0f);
                     if (++sample < B.spf)
                     {
                         // next sample of the same dispatch continues the RNG stream
                         pid += B.n_pixels;
-                        camera_ray(F, px, py, P.rng, P.origin, P.dir);
-                        T = v3(1.0f, 1.0f, 1.0f);
-                        L = v3(0.0f, 0.0f, 0.0f);
+                        ps = camera_path(F, px, py, ps.rng);
                         bounce = 0u;
-                        R = make_ray_ctx(P.origin, P.dir, tmax);
+                        R = make_ray_ctx(ps.origin, ps.dir, tmax);
                         best = no_hit(tmax);
                         ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
                         tg = make_uint2(0u, 0u);
@@ -395,7 +360,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 }
                 else
                 {
-                    finish_path(B, pid, L, P.rng);
+                    finish_path(B, pid, ps.radiance, ps.rng);
                     mode = kIdle;
                 }
             }
