@@ -254,7 +254,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // rarer phases (pulling new paths, shading, triangle tests) run when
     // enough lanes of the wave want them, or when a lane has nothing else left.
     constexpr uint32_t kIdle = 0u, kTrav = 1u, kShade = 2u;
-    constexpr uint32_t kFetchMin = 8u, kShadeMin = 16u; // lanes that must want a phase before it runs
+    constexpr uint32_t kFetchMin = 16u, kShadeMin = 16u; // lanes that must want a phase before it runs
     uint32_t mode = kIdle;
     bool exhausted = n == 0u;
     PathState ps = camera_path(F, 0u, 0u, 0u);
