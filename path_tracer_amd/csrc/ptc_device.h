@@ -619,37 +619,22 @@ PTC_DEV void node_eval(const uint4 w0, const uint4 w1, const uint4 w2, const uin
             bits_of[4 * half + k] = ((count4 >> (8 * k)) & 0xffu) << ((index4 >> (8 * k)) & 0xffu);
         }
     }
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz};
-    const f2 bnx2 = {bnx, bnx}, bny2 = {bny, bny}, bnz2 = {bnz, bnz};
-    const f2 bfx2 = {bfx, bfx}, bfy2 = {bfy, bfy}, bfz2 = {bfz, bfz};
     uint32_t hitmask = 0u;
 #pragma unroll
-    for (int c = 0; c < 8; c += 2)
+    for (int c = 0; c < 8; ++c)
     {
-        // two slots at a time so the six plane distances use packed fma
         const int k = c & 3;
-        const f2 qnx = {ubyte_f(c < 4 ? nx0 : nx1, k), ubyte_f(c < 4 ? nx0 : nx1, k + 1)};
-        const f2 qny = {ubyte_f(c < 4 ? ny0 : ny1, k), ubyte_f(c < 4 ? ny0 : ny1, k + 1)};
-        const f2 qnz = {ubyte_f(c < 4 ? nz0 : nz1, k), ubyte_f(c < 4 ? nz0 : nz1, k + 1)};
-        const f2 qfx = {ubyte_f(c < 4 ? fx0 : fx1, k), ubyte_f(c < 4 ? fx0 : fx1, k + 1)};
-        const f2 qfy = {ubyte_f(c < 4 ? fy0 : fy1, k), ubyte_f(c < 4 ? fy0 : fy1, k + 1)};
-        const f2 qfz = {ubyte_f(c < 4 ? fz0 : fz1, k), ubyte_f(c < 4 ? fz0 : fz1, k + 1)};
-        const f2 tnx = __builtin_elementwise_fma(qnx, sx2, bnx2);
-        const f2 tny = __builtin_elementwise_fma(qny, sy2, bny2);
-        const f2 tnz = __builtin_elementwise_fma(qnz, sz2, bnz2);
-        const f2 tfx = __builtin_elementwise_fma(qfx, sx2, bfx2);
-        const f2 tfy = __builtin_elementwise_fma(qfy, sy2, bfy2);
-        const f2 tfz = __builtin_elementwise_fma(qfz, sz2, bfz2);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-        {
-            // (slab distances are finite for finite input, so the hardware
-            // min / max and the compare-select forms agree)
-            const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx[j], tny[j]), __builtin_fmaxf(tnz[j], 0.0f));
-            const float tf = __builtin_fminf(__builtin_fminf(tfx[j], tfy[j]), __builtin_fminf(tfz[j], tlim));
-            hitmask |= tn <= tf ? bits_of[c + j] : 0u;
-        }
+        const float tnx = __builtin_fmaf(ubyte_f(c < 4 ? nx0 : nx1, k), sx, bnx);
+        const float tny = __builtin_fmaf(ubyte_f(c < 4 ? ny0 : ny1, k), sy, bny);
+        const float tnz = __builtin_fmaf(ubyte_f(c < 4 ? nz0 : nz1, k), sz, bnz);
+        const float tfx = __builtin_fmaf(ubyte_f(c < 4 ? fx0 : fx1, k), sx, bfx);
+        const float tfy = __builtin_fmaf(ubyte_f(c < 4 ? fy0 : fy1, k), sy, bfy);
+        const float tfz = __builtin_fmaf(ubyte_f(c < 4 ? fz0 : fz1, k), sz, bfz);
+        // (slab distances are finite for finite input, so the hardware min / max
+        // and the compare-select forms agree)
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
+        hitmask |= tn <= tf ? bits_of[c] : 0u;
     }
     ng.x = w1.x;
     ng.y = (hitmask & kNodeBits) | imask;
@@ -789,6 +774,67 @@ PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *ld
                 break;
             }
             ng = stack_pop<kLds>(lds_stack, stride, spill, sp);
+        }
+    }
+    return best;
+}
+
+// Same closest hit, different schedule: every loop iteration runs at most one
+// node visit and one triangle test per lane, and triangle groups found while
+// older ones are pending wait on the stack. Lanes of a wave then stay in step
+// (nobody waits through another lane's triangle loop), at the price of a
+// later-shrinking t limit, so this order visits slightly more nodes than
+// trace_closest(). The result is identical: the closest hit does not depend on
+// the visit order.
+template <int kLds = kLdsStack>
+PTC_DEV Hit trace_closest_interleaved(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_stack,
+                                      uint32_t stride)
+{
+    Hit best = no_hit(tmax);
+    if (S.n_tris == 0u)
+    {
+        return best;
+    }
+    const RayCtx R = make_ray_ctx(o, d, tmax);
+    uint2 spill[kStackTotal - kLds];
+    int sp = 0;
+    uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
+    for (;;)
+    {
+        if (!(ng.y & kNodeBits) && tg.y == 0u)
+        {
+            if (sp == 0)
+            {
+                break;
+            }
+            const uint2 e = stack_pop<kLds>(lds_stack, stride, spill, sp);
+            if (e.y & kNodeBits)
+            {
+                ng = e;
+            }
+            else
+            {
+                tg = e;
+            }
+        }
+        if (ng.y & kNodeBits)
+        {
+            const uint32_t node_idx = next_child(ng, R.octinv);
+            if (ng.y & kNodeBits)
+            {
+                stack_push<kLds>(lds_stack, stride, spill, sp, ng);
+            }
+            if (tg.y)
+            {
+                stack_push<kLds>(lds_stack, stride, spill, sp, tg);
+            }
+            node_test(S, R, best.t, node_idx, ng, tg);
+        }
+        if (tg.y)
+        {
+            const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
+            tg.y &= tg.y - 1u;
+            tri_test(S, R, tg.x + i, best);
         }
     }
     return best;

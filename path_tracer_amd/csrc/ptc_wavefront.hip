@@ -119,11 +119,12 @@ PTC_DEV PathState camera_path(const DFrame &F, uint32_t px, uint32_t py, uint32_
     return ps;
 }
 
+constexpr int kPrimaryLds = 16; // LDS stack entries per lane (two pushes per level)
 __global__ void __launch_bounds__(kBlock)
 k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample,
              uint32_t n_disp)
 {
-    __shared__ uint2 s_stack[kLdsStack * kBlock];
+    __shared__ uint2 s_stack[kPrimaryLds * kBlock];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tiles_x = (F.width + 15u) >> 4;
     // consecutive blocks are the dispatches of one tile, so the blocks resident
@@ -153,7 +154,8 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
         alive = F.max_depth > 0u;
         if (alive)
         {
-            const Hit h = trace_closest<false>(S, ps.origin, ps.dir, F.tmax, s_stack + threadIdx.x, kBlock, nullptr);
+            const Hit h = trace_closest_interleaved<kPrimaryLds>(S, ps.origin, ps.dir, F.tmax,
+                                                                 s_stack + threadIdx.x, kBlock);
             alive = path_bounce(S, h, ps) && F.max_depth > 1u;
         }
         if (!alive)
@@ -254,7 +256,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // rarer phases (pulling new paths, shading, triangle tests) run when
     // enough lanes of the wave want them, or when a lane has nothing else left.
     constexpr uint32_t kIdle = 0u, kTrav = 1u, kShade = 2u;
-    constexpr uint32_t kFetchMin = 16u, kShadeMin = 16u; // lanes that must want a phase before it runs
+    constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 16u; // lanes that must want a phase before it runs
     uint32_t mode = kIdle;
     bool exhausted = n == 0u;
     PathState ps = camera_path(F, 0u, 0u, 0u);
