@@ -854,7 +854,9 @@ PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, vec3 origin, vec3 dir, u
     ps.rng = rng_io;
     for (uint32_t bounces = 0; bounces < f.max_depth; ++bounces)
     {
-        const Hit h = trace_closest<kCount>(S, ps.origin, ps.dir, f.tmax, lds_stack, stride, ctr);
+        // counting runs use the reproducible visit order, plain runs the faster one
+        const Hit h = kCount ? trace_closest<true>(S, ps.origin, ps.dir, f.tmax, lds_stack, stride, ctr)
+                             : trace_closest_interleaved(S, ps.origin, ps.dir, f.tmax, lds_stack, stride);
         ++rays;
         if (!path_bounce(S, h, ps))
         {
