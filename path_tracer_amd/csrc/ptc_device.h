@@ -276,11 +276,43 @@ PTC_DEV vec3 load3(const float *__restrict__ p)
 // selected by the instance's kind (the SBT record offset).
 PTC_DEV Payload closest_hit(const DScene &S, vec3 ray_dir, const Hit &h, uint32_t rng)
 {
-    const DInstance *__restrict__ I = &S.instances[h.instance];
-    const uint32_t *__restrict__ idx = S.indices + 3u * (size_t)(I->tri_offset + h.primitive);
-    const uint32_t i0 = idx[0] + I->vtx_offset;
-    const uint32_t i1 = idx[1] + I->vtx_offset;
-    const uint32_t i2 = idx[2] + I->vtx_offset;
+    // The instance record (transforms, offsets, kind). Most scenes have a
+    // handful of instances, so the lanes of a wave usually want the same one:
+    // fetch it once through the scalar cache then, per lane otherwise.
+    float o2w[12], w2o[12];
+    uint32_t kind, vtx_offset, tri_offset;
+    const uint32_t first_inst = __builtin_amdgcn_readfirstlane(h.instance);
+    if (__builtin_amdgcn_ballot_w64(h.instance != first_inst) == 0ull)
+    {
+        typedef const __attribute__((address_space(4))) uint32_t *scalar_words;
+        const scalar_words w = (scalar_words)(uintptr_t)(S.instances + first_inst);
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+        {
+            o2w[i] = __uint_as_float(w[i]);
+            w2o[i] = __uint_as_float(w[12 + i]);
+        }
+        kind = w[24];
+        vtx_offset = w[25];
+        tri_offset = w[26];
+    }
+    else
+    {
+        const DInstance *__restrict__ I = &S.instances[h.instance];
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+        {
+            o2w[i] = I->o2w[i];
+            w2o[i] = I->w2o[i];
+        }
+        kind = I->kind;
+        vtx_offset = I->vtx_offset;
+        tri_offset = I->tri_offset;
+    }
+    const uint32_t *__restrict__ idx = S.indices + 3u * (size_t)(tri_offset + h.primitive);
+    const uint32_t i0 = idx[0] + vtx_offset;
+    const uint32_t i1 = idx[1] + vtx_offset;
+    const uint32_t i2 = idx[2] + vtx_offset;
     const vec3 v0 = load3(S.positions + 3u * (size_t)i0);
     const vec3 v1 = load3(S.positions + 3u * (size_t)i1);
     const vec3 v2 = load3(S.positions + 3u * (size_t)i2);
@@ -290,10 +322,10 @@ PTC_DEV Payload closest_hit(const DScene &S, vec3 ray_dir, const Hit &h, uint32_
     const float bx = 1.0f - h.u - h.v, by = h.u, bz = h.v;
     const vec3 object_position = (v0 * bx + v1 * by) + v2 * bz;
     const vec3 object_normal = (n0 * bx + n1 * by) + n2 * bz;
-    const vec3 world_normal = normalize(xform_normal_rowvec(I->w2o, object_normal));
-    const vec3 world_position = xform_point(I->o2w, object_position);
+    const vec3 world_normal = normalize(xform_normal_rowvec(w2o, object_normal));
+    const vec3 world_position = xform_point(o2w, object_position);
     const vec3 nrm = faceforward(world_normal, ray_dir, world_normal);
-    return material_scatter(I->kind, ray_dir, world_position, nrm, rng);
+    return material_scatter(kind, ray_dir, world_position, nrm, rng);
 }
 
 // ---- miss program: shader.rmiss:11-29 ----------------------------------------
@@ -706,12 +738,20 @@ PTC_DEV void tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index, Hit 
 // of the lane at lds[e * stride]), deeper ones in a private spill array. The
 // pieces are passed separately (not as one struct) so that the depth counter
 // stays in a register and the LDS pointer keeps its address space.
+// (lds always points into a __shared__ array. It is cast to the LDS address
+// space explicitly: with a generic pointer the compiler folds the LDS and the
+// spill access into one flat-pointer access, and flat loads take the slower
+// vector-memory path on every pop.)
+typedef uint32_t stack_entry_bits __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) stack_entry_bits *lds_stack_ptr;
+
 template <int kLds>
 PTC_DEV void stack_push(uint2 *lds, uint32_t stride, uint2 *spill, int &sp, uint2 e)
 {
     if (sp < kLds)
     {
-        lds[sp * stride] = e;
+        const stack_entry_bits v = {e.x, e.y};
+        ((lds_stack_ptr)lds)[sp * stride] = v;
     }
     else if (sp < kStackTotal)
     {
@@ -721,10 +761,15 @@ PTC_DEV void stack_push(uint2 *lds, uint32_t stride, uint2 *spill, int &sp, uint
 }
 
 template <int kLds>
-PTC_DEV uint2 stack_pop(const uint2 *lds, uint32_t stride, const uint2 *spill, int &sp)
+PTC_DEV uint2 stack_pop(uint2 *lds, uint32_t stride, const uint2 *spill, int &sp)
 {
     --sp;
-    return sp < kLds ? lds[sp * stride] : spill[sp - kLds];
+    if (sp < kLds)
+    {
+        const stack_entry_bits v = ((lds_stack_ptr)lds)[sp * stride];
+        return make_uint2(v.x, v.y);
+    }
+    return spill[sp - kLds];
 }
 
 // Closest hit of one ray, in a fixed order: visit the nearest pending child,
