@@ -276,6 +276,42 @@ int ptc_synchronize(ptc_context *ctx);
  * ptc_last_error(). */
 int ptc_write_png(ptc_film *film, const char *file_name);
 
+/* read_hdr_image() (src/utility.cpp:75-92; the reference calls stb_image's
+ * stbi_loadf(file, &w, &h, &channels, 4) and uploads the result as the
+ * RGBA32F environment map, src/renderer.cpp:1842-1860): decode a Radiance
+ * .hdr file (RGBE, flat or run-length-encoded scanlines) to RGBA float, rows
+ * top to bottom, alpha 1. With rgba == NULL only the size is returned.
+ * capacity_floats must be >= 4 * width * height. Host-side; no GPU needed.
+ * Returns PTC_OK, PTC_E_IO (message in ptc_last_error()) or PTC_E_INVALID. */
+int ptc_read_hdr(const char *file_name, uint32_t *width, uint32_t *height, float *rgba,
+                 size_t capacity_floats);
+
+/* Scene import, the part of open_scene() that runs before
+ * create_render_resources() (src/application.cpp:150-200): the reference hands
+ * the file to Assimp (third-party, v5.3.1) with PreTransformVertices +
+ * normalisation to [-1, 1], Triangulate, FindDegenerates, SortByPType (lines
+ * and points removed), FixInfacingNormals, GenSmoothNormals with a maximum
+ * smoothing angle of 80 degrees and JoinIdenticalVertices, then reads
+ * mVertices / mNormals / mFaces of the meshes. This importer reads Wavefront
+ * OBJ and Stanford PLY (ascii and binary) files and applies the same steps;
+ * mesh i is returned as the ptc_mesh_desc that ptc_scene_create() takes.
+ * Pointers in the descriptor stay valid until ptc_mesh_file_close().
+ * Failure: PTC_E_IO with the importer's message ("Scene has no meshes", ...)
+ * in ptc_last_error(). Host-side; no GPU needed. */
+typedef struct ptc_mesh_file ptc_mesh_file;
+#define PTC_IMPORT_NO_NORMALIZE 1u /* keep file coordinates (no AI_CONFIG_PP_PTV_NORMALIZE) */
+#define PTC_IMPORT_NO_JOIN 2u      /* keep one vertex per triangle corner */
+typedef struct ptc_import_options
+{
+    float max_smoothing_angle_deg; /* AI_CONFIG_PP_GSN_MAX_SMOOTHING_ANGLE; 0 = 80 */
+    uint32_t flags;                /* PTC_IMPORT_* */
+    uint32_t reserved[6];
+} ptc_import_options;
+int ptc_mesh_file_open(const char *file_name, const ptc_import_options *options, ptc_mesh_file **out);
+uint32_t ptc_mesh_file_mesh_count(const ptc_mesh_file *file);
+int ptc_mesh_file_get_mesh(const ptc_mesh_file *file, uint32_t index, ptc_mesh_desc *out);
+void ptc_mesh_file_close(ptc_mesh_file *file);
+
 /* Element-wise evaluation of the device math primitives the kernels use, so
  * a checker can compare them with its own: fn 0 sincos(a) -> out, out2;
  * 1 log(a); 2 acos(a); 3 atan2(a, b); 4 a / b; 5 sqrt(a);

@@ -3,23 +3,27 @@
 // progressively with draw_frame() until samples_to_render is reached, and
 // writes the PNG that the reference's "save" dialog would write.
 //
-//   ptc_headless [<file.obj>] [--width W] [--height H] [--spp N] [--spf N]
-//                [--depth D] [--megakernel] [--out image.png] [--device N]
+//   ptc_headless [<file.obj|.ply>] [--width W] [--height H] [--spp N] [--spf N]
+//                [--depth D] [--megakernel] [--env sky.hdr] [--out image.png]
+//                [--device N]
 //
-// Without a file it renders a built-in Cornell box. With a Wavefront OBJ file it
-// does what the reference does at HEAD: takes the first mesh, normalises it to
-// [-1, 1] (AI_CONFIG_PP_PTV_NORMALIZE, src/application.cpp:161), generates
-// smooth vertex normals when the file has none, and instantiates it four times
-// with the transforms and material kinds of src/renderer.cpp:1147-1174.
+// --env loads a Radiance .hdr file as the environment map, as the reference
+// does with its hard-coded "powerplant.hdr" (src/renderer.cpp:1842); without it
+// the sky is the two-tone one kept under "#if 0" in shader.rmiss:13-18.
+//
+// Without a file it renders a built-in box scene. With a Wavefront OBJ or
+// Stanford PLY file it does what the reference does at HEAD: imports it with
+// the post-processing of src/application.cpp:150-189 (normalised to [-1, 1],
+// smooth normals where the file has none, identical vertices joined), takes
+// mesh 0 and instantiates it four times with the transforms and material kinds
+// of src/renderer.cpp:1147-1174.
 #include "ptc_renderer.hpp"
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <fstream>
 #include <iostream>
-#include <sstream>
 
 using namespace ptc_host;
 
@@ -85,99 +89,6 @@ Scene_arrays builtin_box()
     return s;
 }
 
-// Minimal Wavefront OBJ reader: v, vn (optional) and f records; polygons are
-// fan-triangulated; all groups are merged into one mesh ("mesh 0").
-Scene_arrays::Mesh load_obj(const char *file_name)
-{
-    std::ifstream in(file_name);
-    if (!in)
-    {
-        throw std::runtime_error(std::string("cannot open ") + file_name);
-    }
-    Scene_arrays::Mesh m;
-    std::string line;
-    while (std::getline(in, line))
-    {
-        std::istringstream ls(line);
-        std::string tag;
-        ls >> tag;
-        if (tag == "v")
-        {
-            float x, y, z;
-            ls >> x >> y >> z;
-            m.positions.insert(m.positions.end(), {x, y, z});
-        }
-        else if (tag == "f")
-        {
-            std::vector<std::uint32_t> idx;
-            std::string tok;
-            const long nv = static_cast<long>(m.positions.size() / 3);
-            while (ls >> tok)
-            {
-                long i = std::strtol(tok.c_str(), nullptr, 10);
-                i = i < 0 ? nv + i : i - 1;
-                if (i < 0 || i >= nv)
-                {
-                    throw std::runtime_error("OBJ face index out of range");
-                }
-                idx.push_back(static_cast<std::uint32_t>(i));
-            }
-            for (std::size_t k = 2; k < idx.size(); ++k)
-            {
-                m.indices.insert(m.indices.end(), {idx[0], idx[k - 1], idx[k]});
-            }
-        }
-    }
-    if (m.indices.empty())
-    {
-        throw std::runtime_error("Scene has no meshes"); // message of src/application.cpp:200
-    }
-    // normalise to [-1, 1] about the bounding-box centre
-    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
-    for (std::size_t v = 0; v < m.positions.size(); v += 3)
-    {
-        for (int k = 0; k < 3; ++k)
-        {
-            lo[k] = std::min(lo[k], m.positions[v + k]);
-            hi[k] = std::max(hi[k], m.positions[v + k]);
-        }
-    }
-    const float half = 0.5f * std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]});
-    for (std::size_t v = 0; v < m.positions.size(); v += 3)
-    {
-        for (int k = 0; k < 3; ++k)
-        {
-            m.positions[v + k] = (m.positions[v + k] - 0.5f * (lo[k] + hi[k])) / half;
-        }
-    }
-    // area-weighted smooth vertex normals
-    m.normals.assign(m.positions.size(), 0.0f);
-    for (std::size_t t = 0; t < m.indices.size(); t += 3)
-    {
-        const std::uint32_t i[3] = {m.indices[t], m.indices[t + 1], m.indices[t + 2]};
-        const vec3 a {m.positions[3 * i[0]], m.positions[3 * i[0] + 1], m.positions[3 * i[0] + 2]};
-        const vec3 b {m.positions[3 * i[1]], m.positions[3 * i[1] + 1], m.positions[3 * i[1] + 2]};
-        const vec3 c {m.positions[3 * i[2]], m.positions[3 * i[2] + 1], m.positions[3 * i[2] + 2]};
-        const vec3 n = detail::cross(detail::sub(b, a), detail::sub(c, a));
-        for (int k = 0; k < 3; ++k)
-        {
-            m.normals[3 * i[k]] += n.x;
-            m.normals[3 * i[k] + 1] += n.y;
-            m.normals[3 * i[k] + 2] += n.z;
-        }
-    }
-    for (std::size_t v = 0; v < m.normals.size(); v += 3)
-    {
-        const vec3 n {m.normals[v], m.normals[v + 1], m.normals[v + 2]};
-        const float len = detail::length(n);
-        const vec3 u = len > 0.0f ? detail::mul(n, 1.0f / len) : vec3 {0.0f, 1.0f, 0.0f};
-        m.normals[v] = u.x;
-        m.normals[v + 1] = u.y;
-        m.normals[v + 2] = u.z;
-    }
-    return m;
-}
-
 } // namespace
 
 int main(int argc, char **argv)
@@ -185,7 +96,7 @@ int main(int argc, char **argv)
     try
     {
         const char *file = nullptr;
-        std::string out = "render.png";
+        std::string out = "render.png", env;
         std::uint32_t width = 640, height = 480, spp = 64, spf = 1, depth = 32; // src/application.cpp:206-207
         int device = 0;
         bool megakernel = false;
@@ -205,12 +116,13 @@ int main(int argc, char **argv)
             else if (a == "--spf") spf = std::strtoul(next(), nullptr, 10);
             else if (a == "--depth") depth = std::strtoul(next(), nullptr, 10);
             else if (a == "--out") out = next();
+            else if (a == "--env") env = next();
             else if (a == "--device") device = std::atoi(next());
             else if (a == "--megakernel") megakernel = true;
             else if (a[0] == '-')
             {
-                std::cerr << "Usage: " << argv[0] << " [<file.obj>] [--width W] [--height H] [--spp N] [--spf N] "
-                          << "[--depth D] [--megakernel] [--out image.png] [--device N]\n";
+                std::cerr << "Usage: " << argv[0] << " [<file.obj|.ply>] [--width W] [--height H] [--spp N] [--spf N] "
+                          << "[--depth D] [--megakernel] [--env sky.hdr] [--out image.png] [--device N]\n";
                 return EXIT_FAILURE;
             }
             else file = argv[i];
@@ -219,7 +131,8 @@ int main(int argc, char **argv)
         Scene_arrays scene;
         if (file)
         {
-            scene.meshes.push_back(load_obj(file));
+            // the reference uploads mesh 0 only (src/renderer.cpp:1818-1838)
+            scene.meshes.push_back(std::move(import_scene(file).meshes.front()));
             // the four instances of src/renderer.cpp:1147-1159, kind = i % 4
             scene.instances = {instance(0, 0, 1.0f, -1.0f), instance(0, 1, 0.7f, 1.0f), instance(0, 2, 0.2f),
                                instance(0, 3, 0.8f, 0.0f, 0.0f, 0.8f)};
@@ -227,6 +140,14 @@ int main(int argc, char **argv)
         else
         {
             scene = builtin_box();
+        }
+
+        if (!env.empty())
+        {
+            Image_f32 sky = read_hdr_image(env.c_str());
+            scene.envmap_width = sky.width;
+            scene.envmap_height = sky.height;
+            scene.envmap_rgba = std::move(sky.data);
         }
 
         Render_context context = create_context(device);

@@ -150,6 +150,47 @@ struct Render_resources
     }
 };
 
+// The import half of open_scene() (src/application.cpp:150-200): the meshes of
+// a Wavefront OBJ or Stanford PLY file after the post-processing the reference
+// configures Assimp with. Instances and the sky are left to the caller. Throws
+// with the importer's message ("Scene has no meshes", ...) on failure.
+[[nodiscard]] inline Scene_arrays import_scene(const char *file_name, const ptc_import_options *options = nullptr)
+{
+    ptc_mesh_file *file = nullptr;
+    detail::check(ptc_mesh_file_open(file_name, options, &file), "open_scene");
+    Scene_arrays scene;
+    for (std::uint32_t i = 0; i < ptc_mesh_file_mesh_count(file); ++i)
+    {
+        ptc_mesh_desc d {};
+        ptc_mesh_file_get_mesh(file, i, &d);
+        Scene_arrays::Mesh m;
+        m.positions.assign(d.positions, d.positions + 3 * static_cast<std::size_t>(d.n_vertices));
+        m.normals.assign(d.normals, d.normals + 3 * static_cast<std::size_t>(d.n_vertices));
+        m.indices.assign(d.indices, d.indices + 3 * static_cast<std::size_t>(d.n_triangles));
+        scene.meshes.push_back(std::move(m));
+    }
+    ptc_mesh_file_close(file);
+    return scene;
+}
+
+// Image<float> of src/utility.hpp:16-22 and read_hdr_image (src/utility.cpp:75-92):
+// RGBA32F, rows top to bottom; throws with the decoder's reason on failure.
+struct Image_f32
+{
+    std::vector<float> data;
+    std::uint32_t width {0}, height {0};
+};
+
+[[nodiscard]] inline Image_f32 read_hdr_image(const char *file_name)
+{
+    Image_f32 image;
+    detail::check(ptc_read_hdr(file_name, &image.width, &image.height, nullptr, 0), "read_hdr_image");
+    image.data.resize(static_cast<std::size_t>(4) * image.width * image.height);
+    detail::check(ptc_read_hdr(file_name, &image.width, &image.height, image.data.data(), image.data.size()),
+                  "read_hdr_image");
+    return image;
+}
+
 // create_context (src/renderer.hpp:256); the window argument has no meaning here.
 [[nodiscard]] inline Render_context create_context(int device_ordinal = 0)
 {

@@ -79,6 +79,13 @@ class EnvmapDesc(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
+class ImportOptions(C.Structure):
+    _fields_ = [("max_smoothing_angle_deg", C.c_float), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+
+
+IMPORT_NO_NORMALIZE, IMPORT_NO_JOIN = 1, 2
+
+
 class BuildOptions(C.Structure):
     _fields_ = [("search_radius", C.c_uint32), ("reserved", C.c_uint32 * 7)]
 
@@ -116,7 +123,8 @@ EXPORTS = [
     "ptc_trace_rays", "ptc_trace_rays_device", "ptc_get_stats", "ptc_render_times",
     "ptc_phase_times",
     "ptc_reset_stats",
-    "ptc_synchronize", "ptc_write_png", "ptc_math_eval",
+    "ptc_synchronize", "ptc_write_png", "ptc_math_eval", "ptc_read_hdr",
+    "ptc_mesh_file_open", "ptc_mesh_file_mesh_count", "ptc_mesh_file_get_mesh", "ptc_mesh_file_close",
 ]
 
 _lib = None
@@ -163,6 +171,13 @@ def lib():
         L.ptc_synchronize.argtypes = [vp]
         L.ptc_write_png.argtypes = [vp, C.c_char_p]
         L.ptc_math_eval.argtypes = [vp, C.c_int, vp, vp, vp, vp, sz]
+        L.ptc_read_hdr.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp, sz]
+        L.ptc_mesh_file_open.argtypes = [C.c_char_p, C.POINTER(ImportOptions), C.POINTER(vp)]
+        L.ptc_mesh_file_mesh_count.argtypes = [vp]
+        L.ptc_mesh_file_mesh_count.restype = u32
+        L.ptc_mesh_file_get_mesh.argtypes = [vp, u32, C.POINTER(MeshDesc)]
+        L.ptc_mesh_file_close.argtypes = [vp]
+        L.ptc_mesh_file_close.restype = None
         _lib = L
     return _lib
 
@@ -525,6 +540,45 @@ def draw_frame(context: RenderContext, render_resources: RenderResources, camera
 def reset_render(render_resources: RenderResources) -> None:
     """reset_render() (src/renderer.cpp:2236-2239)."""
     _check(lib().ptc_film_reset(render_resources.film))
+
+
+def import_meshes(file_name: str, max_smoothing_angle: float = 80.0, normalize: bool = True,
+                  join_identical_vertices: bool = True) -> list:
+    """The import half of open_scene() (src/application.cpp:150-200): reads a
+    Wavefront OBJ or Stanford PLY file and post-processes it the way the
+    reference configures Assimp (normalise to [-1, 1], triangulate, drop
+    degenerate faces, smooth normals up to 80 degrees where the file has none,
+    join identical vertices). Returns the meshes; raises PtcError with the
+    importer's message otherwise."""
+    opts = ImportOptions()
+    opts.max_smoothing_angle_deg = max_smoothing_angle
+    opts.flags = (0 if normalize else IMPORT_NO_NORMALIZE) | (0 if join_identical_vertices else IMPORT_NO_JOIN)
+    h = C.c_void_p()
+    _check(lib().ptc_mesh_file_open(os.fsencode(file_name), C.byref(opts), C.byref(h)))
+    try:
+        meshes = []
+        for i in range(lib().ptc_mesh_file_mesh_count(h)):
+            d = MeshDesc()
+            _check(lib().ptc_mesh_file_get_mesh(h, i, C.byref(d)))
+            nv, nt = d.n_vertices, d.n_triangles
+            as_f32 = lambda ptr: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), (nv, 3)).copy()
+            idx = np.ctypeslib.as_array(C.cast(d.indices, C.POINTER(C.c_uint32)), (nt, 3)).copy()
+            meshes.append(Mesh(as_f32(d.positions), as_f32(d.normals), idx))
+        return meshes
+    finally:
+        lib().ptc_mesh_file_close(h)
+
+
+def read_hdr_image(file_name: str) -> np.ndarray:
+    """read_hdr_image() (src/utility.cpp:75-92): a Radiance .hdr file as an
+    (height, width, 4) float32 array, rows top to bottom, alpha 1. Raises
+    PtcError with the decoder's reason on failure, as the reference throws."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    name = os.fsencode(file_name)
+    _check(lib().ptc_read_hdr(name, C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 4), np.float32)
+    _check(lib().ptc_read_hdr(name, C.byref(w), C.byref(h), out.ctypes.data, out.size))
+    return out
 
 
 def write_to_png(context: RenderContext, render_resources: RenderResources, file_name: str) -> str:

@@ -35,8 +35,27 @@ def dump(name, obj):
     print("wrote", name)
 
 
+def hdr_fixture():
+    # small .hdr files (both scanline encodings) with the texels the format defines
+    import base64
+    from oracle import hdr_image as H
+    rng = np.random.default_rng(11)
+    img = (rng.random((6, 20, 3), dtype=np.float32) * np.float32(8.0)).astype(np.float32)
+    img[0] = np.float32(0.75)
+    img[5, :4] = 0.0
+    img[2, 3] = np.float32(40000.0)
+    rgbe = H.float_to_rgbe(img)
+    cases = []
+    for name, rle in (("sky_rle.hdr", True), ("sky_flat.hdr", False)):
+        data = H.encode(rgbe, rle=rle)
+        cases.append({"name": name, "width": 20, "height": 6, "file_b64": base64.b64encode(data).decode(),
+                      "rgba_bits": hx(H.rgbe_to_float(rgbe))})
+    dump("hdr_image.json", {"cases": cases})
+
+
 def main():
     O.build()
+    hdr_fixture()
     # (i) hash / random streams, incl. the 1.0 return and the zero fixed point
     seeds = [1, 2463534242, 0xFFFFFFFF, 0, O.seed(0, 0), O.seed(12345, 77)]
     rng = {"hash": {str(x): O.hash32(x) for x in [0, 1, 2, 255, 65536, 0xDEADBEEF, 0xFFFFFFFF]},

@@ -45,7 +45,34 @@ def test_obj_file_as_the_reference_scene(tmp_path, ctx):
     png = str(tmp_path / "knot.png")
     log = run_cli(str(obj), "--width", "80", "--height", "60", "--spp", "4", "--out", png)
     assert f"triangles {4 * m.indices.shape[0]}" in log  # four instances of mesh 0
-    assert np.asarray(Image.open(png)).shape == (60, 80, 4)
+    img = np.asarray(Image.open(png))
+    assert img.shape == (60, 80, 4)
+    # the Python mirror importing the same file and rendering the same schedule gives the same picture
+    rr = R.create_render_resources(ctx, 80, 60, scenes.ref4_scene(R.import_meshes(str(obj))[0]))
+    cam = R.default_camera(80, 60)
+    for frame in range(4):
+        rr.render(cam, frame=frame)
+    assert np.array_equal(rr.read_rgba8(), img)
+    rr.close()
+
+
+def test_env_map_from_hdr_file(tmp_path, ctx):
+    """--env sky.hdr: the CLI's picture equals the Python mirror's render of the
+    same scene with the same decoded map (both go through ptc_read_hdr)."""
+    from oracle import hdr_image as H
+    sky = scenes.procedural_sky(64, 32)
+    hdr = tmp_path / "sky.hdr"
+    hdr.write_bytes(H.encode(H.float_to_rgbe(sky[..., :3]), rle=True))
+    decoded = R.read_hdr_image(str(hdr))
+    assert decoded.shape == (32, 64, 4)
+    # shared exponent, 8-bit mantissas: each channel is within 1/128 of the texel's largest channel
+    assert np.all(np.abs(decoded[..., :3] - sky[..., :3]) <= sky[..., :3].max(axis=-1, keepdims=True) / 128)
+    a, b = str(tmp_path / "sky.png"), str(tmp_path / "nosky.png")
+    run_cli("--width", "64", "--height", "48", "--spp", "4", "--depth", "4", "--env", str(hdr), "--out", a)
+    run_cli("--width", "64", "--height", "48", "--spp", "4", "--depth", "4", "--out", b)
+    assert not np.array_equal(np.asarray(Image.open(a)), np.asarray(Image.open(b)))
+    out = subprocess.run([CLI, "--env", str(tmp_path / "missing.hdr")], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "can't fopen" in out.stderr
 
 
 def test_write_to_png_error_message(ctx, tmp_path):

@@ -1,0 +1,165 @@
+"""Scene import of the C ABI (ptc_mesh_file_open: OBJ / PLY + the
+post-processing the reference configures Assimp with,
+src/application.cpp:150-189) against the numpy restatement in
+oracle/mesh_import.py. Host code only: runs without a GPU."""
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import mesh_import as M
+from path_tracer_amd import renderer as R
+from path_tracer_amd import scenes
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def cube():
+    p = np.array([[x, y, z] for x in (0, 2) for y in (0, 4) for z in (0, 1)], np.float32) + np.float32(3.0)
+    quads = [[0, 1, 3, 2], [4, 6, 7, 5], [0, 4, 5, 1], [2, 3, 7, 6], [0, 2, 6, 4], [1, 5, 7, 3]]
+    return p, quads
+
+
+def write_obj(path, p, faces, normals=None):
+    with open(path, "w") as f:
+        f.write("# fixture\no thing\n")
+        for v in p:
+            f.write(f"v {float(v[0])!r} {float(v[1])!r} {float(v[2])!r}\n")
+        if normals is not None:
+            for n in normals:
+                f.write(f"vn {float(n[0])!r} {float(n[1])!r} {float(n[2])!r}\n")
+        for face in faces:
+            if normals is None:
+                f.write("f " + " ".join(str(i + 1) for i in face) + "\n")
+            else:
+                f.write("f " + " ".join(f"{i + 1}//{i + 1}" for i in face) + "\n")
+
+
+def write_ply(path, p, faces, fmt):
+    head = (f"ply\nformat {fmt} 1.0\ncomment fixture\nelement vertex {len(p)}\nproperty float x\n"
+            f"property float y\nproperty float z\nproperty uchar quality\nelement face {len(faces)}\n"
+            "property list uchar int vertex_indices\nend_header\n").encode()
+    with open(path, "wb") as f:
+        f.write(head)
+        if fmt == "ascii":
+            for v in p:
+                f.write(f"{float(v[0])!r} {float(v[1])!r} {float(v[2])!r} 7\n".encode())
+            for face in faces:
+                f.write((str(len(face)) + " " + " ".join(map(str, face)) + "\n").encode())
+        else:
+            e = "<" if fmt == "binary_little_endian" else ">"
+            for v in p:
+                f.write(struct.pack(e + "fffB", *map(float, v), 7))
+            for face in faces:
+                f.write(struct.pack(e + "B" + "i" * len(face), len(face), *face))
+
+
+def check_against_restatement(meshes, p, faces, angle=80.0, normalize=True):
+    assert len(meshes) == 1
+    rp, rn, ri = M.import_polygons(p, faces, angle, normalize)
+    m = meshes[0]
+    assert np.array_equal(m.indices, ri)
+    assert np.array_equal(_bits(m.positions), _bits(rp))
+    assert np.array_equal(_bits(m.normals), _bits(rn))
+
+
+@pytest.mark.parametrize("fmt", ["obj", "ascii", "binary_little_endian", "binary_big_endian"])
+def test_cube_keeps_hard_edges(tmp_path, fmt):
+    p, quads = cube()
+    path = tmp_path / ("cube.obj" if fmt == "obj" else "cube.ply")
+    write_obj(path, p, quads) if fmt == "obj" else write_ply(path, p, quads, fmt)
+    meshes = R.import_meshes(str(path))
+    check_against_restatement(meshes, p, quads)
+    m = meshes[0]
+    # 90-degree creases exceed the 80-degree limit: 6 faces x 4 corners stay distinct
+    assert m.positions.shape == (24, 3) and m.indices.shape == (12, 3)
+    # normalised about the centre along the longest axis (y: extent 4 -> [-1, 1])
+    assert m.positions.min(axis=0).tolist() == [-0.5, -1.0, -0.25]
+    assert m.positions.max(axis=0).tolist() == [0.5, 1.0, 0.25]
+    # every normal is an axis direction pointing away from the centre
+    assert np.all(np.abs(m.normals).sum(axis=1) == 1.0)
+    assert np.all((m.normals * m.positions).sum(axis=1) > 0)
+
+
+def sphere(n_lon=24, n_lat=12):
+    """Latitude-longitude grid with a full ring of coincident vertices at each
+    pole, as exporters write it: the quads touching a pole have two equal corners."""
+    lat = np.linspace(0.0, np.pi, n_lat + 1)
+    lon = np.arange(n_lon) * (2 * np.pi / n_lon)
+    p = np.stack([np.outer(np.sin(lat), np.cos(lon)), np.outer(np.cos(lat), np.ones(n_lon)),
+                  np.outer(np.sin(lat), np.sin(lon))], axis=-1).astype(np.float32)
+    p[0], p[-1] = (0, 1, 0), (0, -1, 0)
+    quads = [[i * n_lon + j, i * n_lon + (j + 1) % n_lon, (i + 1) * n_lon + (j + 1) % n_lon, (i + 1) * n_lon + j]
+             for i in range(n_lat) for j in range(n_lon)]
+    return p.reshape(-1, 3), quads
+
+
+def test_smooth_surface_joins_vertices(tmp_path):
+    p, quads = sphere()
+    path = tmp_path / "sphere.ply"
+    write_ply(path, p, quads, "binary_little_endian")
+    meshes = R.import_meshes(str(path))
+    check_against_restatement(meshes, p, quads)
+    m = meshes[0]
+    n_lon, n_lat = 24, 12
+    # one of the two triangles of every pole quad is degenerate and dropped
+    assert m.indices.shape[0] == 2 * n_lon * n_lat - 2 * n_lon
+    # smooth everywhere: one vertex per distinct position (the pole rings collapse)
+    assert m.positions.shape[0] == n_lon * (n_lat - 1) + 2
+    assert np.allclose(np.linalg.norm(m.normals, axis=1), 1.0, atol=1e-6)
+    assert np.all((m.normals * m.positions).sum(axis=1) > 0.9)  # outward, close to the radius vector
+    # a wider limit changes nothing on a smooth surface; a tiny one splits every corner
+    assert R.import_meshes(str(path), max_smoothing_angle=175.0)[0].positions.shape[0] == m.positions.shape[0]
+    assert R.import_meshes(str(path), max_smoothing_angle=0.01)[0].positions.shape[0] > 3 * m.positions.shape[0]
+
+
+def test_inward_winding_is_fixed(tmp_path):
+    p, quads = sphere()
+    path = tmp_path / "inside_out.obj"
+    write_obj(path, p, [q[::-1] for q in quads])
+    m = R.import_meshes(str(path))[0]
+    assert np.all((m.normals * m.positions).sum(axis=1) > 0.9)  # FixInfacingNormals flipped them outwards
+    a, b, c = (m.positions[m.indices[:, k]] for k in range(3))
+    assert np.all((np.cross(b - a, c - a) * (a + b + c)).sum(axis=1) > 0)  # and the winding with them
+
+
+def test_file_normals_are_kept_and_options(tmp_path):
+    p, quads = cube()
+    n = (p - p.mean(axis=0)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    path = tmp_path / "cube_n.obj"
+    write_obj(path, p, quads, normals=n)
+    m = R.import_meshes(str(path), normalize=False)[0]
+    assert m.positions.shape == (8, 3)  # corner normals given per vertex: corners join
+    order = [int(np.flatnonzero((p == q).all(axis=1))[0]) for q in m.positions]
+    assert np.array_equal(_bits(m.normals), _bits(n[order]))
+    assert np.array_equal(_bits(m.positions), _bits(p[order]))  # file coordinates kept
+    assert R.import_meshes(str(path), join_identical_vertices=False)[0].positions.shape == (36, 3)
+
+
+def test_degenerate_faces_polygons_and_groups(tmp_path):
+    path = tmp_path / "multi.obj"
+    path.write_text(
+        "v 0 0 0\nv 1 0 0\nv 1.5 1 0\nv 0.5 2 0\nv -0.5 1 0\nv 0 0 0\n"
+        "o first\nusemtl a\nf 1 2 3 4 5\nf 1 6 2\nf -6 -5 -4\n"       # pentagon, degenerate, negative indices
+        "usemtl b\nf 1/1 2/2 3/3\nl 1 2\np 3\n")
+    meshes = R.import_meshes(str(path), normalize=False)
+    assert [m.indices.shape[0] for m in meshes] == [4, 1]
+    assert all(np.array_equal(m.normals, np.tile([0, 0, 1], (len(m.normals), 1))) for m in meshes)
+
+
+@pytest.mark.parametrize("content,name,reason", [
+    (b"v 0 0 0\n", "empty.obj", "Scene has no meshes"),
+    (b"f 1 2 3\n", "bad.obj", "out of range"),
+    (b"solid x\n", "x.stl", "No suitable reader"),
+    (b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\n", "cut.ply", "header not terminated"),
+])
+def test_import_errors(tmp_path, content, name, reason):
+    path = tmp_path / name
+    path.write_bytes(content)
+    with pytest.raises(R.PtcError, match=reason):
+        R.import_meshes(str(path))
+    with pytest.raises(R.PtcError, match="Unable to open file"):
+        R.import_meshes(str(tmp_path / "missing.obj"))
