@@ -175,8 +175,15 @@ typedef struct ptc_render_params
      * persistent launch starts right after the first bounce. Does not change
      * results. */
     uint32_t wavefront_bounces;
-    uint32_t reserved[2];
+    /* Tone map applied when the RGBA8 target is written: PBR neutral is what the
+     * reference compiles in (shader.rgen:218-219), ACES is its alternative under
+     * "#else" (shader.rgen:107-135, :220-221). Remembered by the film for
+     * ptc_film_resolve(). */
+    uint32_t tonemap;
+    uint32_t reserved[1];
 } ptc_render_params;
+#define PTC_TONEMAP_PBR_NEUTRAL 0u
+#define PTC_TONEMAP_ACES 1u
 
 typedef struct ptc_stats
 {

@@ -357,6 +357,39 @@ void pt_tonemap_pbr_neutral(const float rgb[3], float out[3])
     st3(out, tonemap_pbr_neutral(ld3(rgb)));
 }
 
+/* shader.rgen:107-135, the alternative the reference keeps under "#else" at
+ * :220-221. GLSL mat3 constructors take columns, so "input_mat * color" has
+ * x = 0.59719 r + 0.35458 g + 0.04823 b, and so on. The multiply-adds are
+ * evaluated as fma chains (GLSL leaves contraction to the compiler). */
+static float aces_fit(float v)
+{
+    const float a = v * (v + 0.0245786f) - 0.000090537f;
+    const float b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+    return a / b;
+}
+
+static float clamp01(float x)
+{
+    return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+}
+
+static pt_vec3 tonemap_aces(pt_vec3 c)
+{
+    const float x = fmaf(0.04823f, c.z, fmaf(0.35458f, c.y, 0.59719f * c.x));
+    const float y = fmaf(0.01566f, c.z, fmaf(0.90834f, c.y, 0.07600f * c.x));
+    const float z = fmaf(0.83777f, c.z, fmaf(0.13383f, c.y, 0.02840f * c.x));
+    const float fx = aces_fit(x), fy = aces_fit(y), fz = aces_fit(z);
+    const float r = fmaf(-0.07367f, fz, fmaf(-0.53108f, fy, 1.60475f * fx));
+    const float g = fmaf(-0.00605f, fz, fmaf(1.10813f, fy, -0.10208f * fx));
+    const float b = fmaf(1.07602f, fz, fmaf(-0.07276f, fy, -0.00327f * fx));
+    return pt_v3(clamp01(r), clamp01(g), clamp01(b));
+}
+
+void pt_tonemap_aces(const float rgb[3], float out[3])
+{
+    st3(out, tonemap_aces(ld3(rgb)));
+}
+
 /* float -> UNORM8: clamp to [0,1] (NaN -> 0), scale by 255, round to nearest
  * even */
 uint8_t pt_unorm8(float x)
@@ -1547,7 +1580,7 @@ static void raygen(const pt_scene *S, const pt_push_constants *push,
         {
             lin = pt_divs(lin, avg[3]);
         }
-        const pt_vec3 rc = tonemap_pbr_neutral(lin);
+        const pt_vec3 rc = rp->tonemap == 1 ? tonemap_aces(lin) : tonemap_pbr_neutral(lin);
         rgba8_px[0] = pt_unorm8(rc.x);
         rgba8_px[1] = pt_unorm8(rc.y);
         rgba8_px[2] = pt_unorm8(rc.z);

@@ -116,6 +116,7 @@ void pt_material_scatter(uint32_t kind, const float dir[3], const float pos[3],
                          float out_color[3], float out_emissivity[3],
                          float *out_attenuation);
 void pt_tonemap_pbr_neutral(const float rgb[3], float out[3]);
+void pt_tonemap_aces(const float rgb[3], float out[3]); /* shader.rgen:107-135 */
 uint8_t pt_unorm8(float x);
 void pt_inverse_affine(const float m[12], float out[12]);
 
@@ -163,6 +164,7 @@ typedef struct
     uint32_t accumulate_sum; /* 0: reference running mean; 1: plain sum */
     int use_bvh;
     int n_threads;       /* 0 = all */
+    int tonemap;         /* 0 = PBR neutral (shader.rgen:218-219), 1 = ACES (:220-221) */
 } pt_render_params;
 
 /* n_frames dispatches of shader.rgen main() over the whole image. push holds

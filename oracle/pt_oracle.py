@@ -84,6 +84,7 @@ class RenderParams(C.Structure):
         ("accumulate_sum", C.c_uint32),
         ("use_bvh", C.c_int),
         ("n_threads", C.c_int),
+        ("tonemap", C.c_int),
     ]
 
 
@@ -136,6 +137,7 @@ def lib():
                                           C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.pt_tonemap_pbr_neutral.argtypes = [C.c_void_p, C.c_void_p]
+        L.pt_tonemap_aces.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_inverse_affine.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_set_math_mode.argtypes = [C.c_int]
         _lib = L
@@ -233,10 +235,13 @@ def material_scatter(kind, ray_dir, pos, nrm, rng_state):
                 rng=s.value)
 
 
-def tonemap(rgb):
+TONEMAP_PBR_NEUTRAL, TONEMAP_ACES = 0, 1
+
+
+def tonemap(rgb, kind=TONEMAP_PBR_NEUTRAL):
     rgb = _f32(rgb)
     out = np.empty(3, np.float32)
-    lib().pt_tonemap_pbr_neutral(_ptr(rgb), _ptr(out))
+    (lib().pt_tonemap_aces if kind == TONEMAP_ACES else lib().pt_tonemap_pbr_neutral)(_ptr(rgb), _ptr(out))
     return out
 
 
@@ -319,9 +324,9 @@ class Scene:
 
     def render(self, push: PushConstants, width, height, accum=None, n_frames=1,
                max_depth=32, tmax=10000.0, accumulate_sum=False, use_bvh=True,
-               n_threads=0, want_rgba8=True):
+               n_threads=0, want_rgba8=True, tonemap=TONEMAP_PBR_NEUTRAL):
         rp = RenderParams(width, height, max_depth, tmax, n_frames,
-                          int(accumulate_sum), int(use_bvh), n_threads)
+                          int(accumulate_sum), int(use_bvh), n_threads, int(tonemap))
         if accum is None:
             accum = np.zeros((height, width, 4), np.float32)
         else:
@@ -334,7 +339,7 @@ class Scene:
 
     def primary_hits(self, push: PushConstants, width, height, tmax=10000.0,
                      use_bvh=True):
-        rp = RenderParams(width, height, 32, tmax, 1, 0, int(use_bvh), 0)
+        rp = RenderParams(width, height, 32, tmax, 1, 0, int(use_bvh), 0, 0)
         ids = np.empty((height, width), np.uint32)
         lib().pt_primary_hits(self.handle, C.byref(push), C.byref(rp), _ptr(ids))
         return ids

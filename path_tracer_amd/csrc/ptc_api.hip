@@ -75,6 +75,7 @@ DFrame make_frame(const ptc_camera &cam, uint32_t width, uint32_t height)
     F.n_frames = 1;
     F.frame_stride = 1;
     F.samples_per_frame = 1;
+    F.tonemap = PTC_TONEMAP_PBR_NEUTRAL;
     return F;
 }
 
@@ -706,6 +707,13 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
     F.max_depth = params->max_depth ? params->max_depth : 32u;
     F.tmax = params->tmax > 0.0f ? params->tmax : 10000.0f;
     F.accumulate_sum = params->accumulate == PTC_ACCUM_SUM ? 1u : 0u;
+    if (params->tonemap > PTC_TONEMAP_ACES)
+    {
+        set_error("ptc_render: unknown tonemap");
+        return PTC_E_INVALID;
+    }
+    F.tonemap = params->tonemap;
+    film->tonemap = params->tonemap;
     F.wavefront_bounces = params->wavefront_bounces;
     // one event pair per call, kept until ptc_render_times() collects them
     constexpr size_t kMaxTimed = 256;

@@ -58,6 +58,7 @@ struct DFrame
     uint32_t n_frames;
     uint32_t frame_stride;
     uint32_t accumulate_sum;
+    uint32_t tonemap; // PTC_TONEMAP_*
     uint32_t wavefront_bounces; // bounces run as trace / shade launch pairs before the drain launch
 };
 
@@ -476,9 +477,36 @@ PTC_DEV uint32_t unorm8(float x)
     return (uint32_t)__builtin_rintf(x * 255.0f);
 }
 
-PTC_DEV uint32_t pack_rgba8(vec3 lin)
+// shader.rgen:107-135 (compiled out in the reference, "#if 1" at :218): the ACES
+// fit of S. Hill. GLSL mat3 constructors are column-major, so the products
+// below are input_mat * color and output_mat * color.
+PTC_DEV float aces_fit(float v)
 {
-    const vec3 rc = tonemap_pbr_neutral(lin);
+    const float a = v * (v + 0.0245786f) - 0.000090537f;
+    const float b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+    return a / b;
+}
+
+PTC_DEV float clamp01(float x)
+{
+    return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+}
+
+PTC_DEV vec3 tonemap_aces(vec3 c)
+{
+    const float x = __builtin_fmaf(0.04823f, c.z, __builtin_fmaf(0.35458f, c.y, 0.59719f * c.x));
+    const float y = __builtin_fmaf(0.01566f, c.z, __builtin_fmaf(0.90834f, c.y, 0.07600f * c.x));
+    const float z = __builtin_fmaf(0.83777f, c.z, __builtin_fmaf(0.13383f, c.y, 0.02840f * c.x));
+    const float fx = aces_fit(x), fy = aces_fit(y), fz = aces_fit(z);
+    const float r = __builtin_fmaf(-0.07367f, fz, __builtin_fmaf(-0.53108f, fy, 1.60475f * fx));
+    const float g = __builtin_fmaf(-0.00605f, fz, __builtin_fmaf(1.10813f, fy, -0.10208f * fx));
+    const float b = __builtin_fmaf(1.07602f, fz, __builtin_fmaf(-0.07276f, fy, -0.00327f * fx));
+    return v3(clamp01(r), clamp01(g), clamp01(b));
+}
+
+PTC_DEV uint32_t pack_rgba8(vec3 lin, uint32_t tonemap)
+{
+    const vec3 rc = tonemap == 1u ? tonemap_aces(lin) : tonemap_pbr_neutral(lin);
     return unorm8(rc.x) | (unorm8(rc.y) << 8) | (unorm8(rc.z) << 16) | 0xff000000u;
 }
 

@@ -79,6 +79,7 @@ struct ptc_film
 {
     ptc_context *ctx = nullptr;
     uint32_t width = 0, height = 0;
+    uint32_t tonemap = 0; // PTC_TONEMAP_* of the last render call
     float4 *d_accum = nullptr;
     uint32_t *d_rgba8 = nullptr;
     bool own_accum = false, own_rgba8 = false;

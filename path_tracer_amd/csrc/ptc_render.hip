@@ -72,7 +72,7 @@ k_render_mega(DScene S, DFrame F, float4 *__restrict__ accum, uint32_t *__restri
         {
             lin = lin / avg.w;
         }
-        rgba8[pixel_index] = pack_rgba8(lin);
+        rgba8[pixel_index] = pack_rgba8(lin, F.tonemap);
     }
     const unsigned long long wr = wave_sum_u64(rays), wp = wave_sum_u64(paths);
     if (lane == 0u)
@@ -142,7 +142,8 @@ k_trace(DScene S, const float *__restrict__ rays, size_t n, float tmax, ptc_hit 
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_resolve(const float4 *__restrict__ accum, uint32_t *__restrict__ rgba8, uint32_t n, int sum_mode)
+k_resolve(const float4 *__restrict__ accum, uint32_t *__restrict__ rgba8, uint32_t n, int sum_mode,
+          uint32_t tonemap)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n)
@@ -155,7 +156,7 @@ k_resolve(const float4 *__restrict__ accum, uint32_t *__restrict__ rgba8, uint32
     {
         lin = lin / a.w;
     }
-    rgba8[i] = pack_rgba8(lin);
+    rgba8[i] = pack_rgba8(lin, tonemap);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -240,7 +241,7 @@ int launch_trace(ptc_context *ctx, const ptc_scene *scene, const float *d_rays, 
 int launch_resolve(ptc_context *ctx, ptc_film *film, int sum_mode)
 {
     const uint32_t n = film->width * film->height;
-    k_resolve<<<blocks_for(n), kBlock, 0, ctx->stream>>>(film->d_accum, film->d_rgba8, n, sum_mode);
+    k_resolve<<<blocks_for(n), kBlock, 0, ctx->stream>>>(film->d_accum, film->d_rgba8, n, sum_mode, film->tonemap);
     PTC_HIP_CHECK(hipGetLastError());
     return PTC_OK;
 }

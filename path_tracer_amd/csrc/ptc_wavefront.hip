@@ -464,7 +464,7 @@ k_wf_resolve(DFrame F, const float4 *__restrict__ radiance, uint32_t n_disp, uin
     {
         lin = lin / avg.w;
     }
-    rgba8[i] = pack_rgba8(lin);
+    rgba8[i] = pack_rgba8(lin, F.tonemap);
 }
 
 // rays traced by the primary pass and by the trace launches of bounces [1, end_b)

@@ -125,6 +125,7 @@ struct Render_resources
     std::uint32_t samples_per_frame {1};
     std::uint32_t max_depth {32};            // literal of shader.rgen:65
     std::uint32_t integrator {PTC_INTEGRATOR_WAVEFRONT};
+    std::uint32_t tonemap {PTC_TONEMAP_PBR_NEUTRAL}; // shader.rgen:218-221
 
     Render_resources() = default;
     Render_resources(const Render_resources &) = delete;
@@ -141,6 +142,7 @@ struct Render_resources
         std::swap(samples_per_frame, o.samples_per_frame);
         std::swap(max_depth, o.max_depth);
         std::swap(integrator, o.integrator);
+        std::swap(tonemap, o.tonemap);
         return *this;
     }
     ~Render_resources()
@@ -247,6 +249,7 @@ inline void draw_frame(Render_context &context, Render_resources &rr, const Came
         p.n_frames = 1;
         p.max_depth = rr.max_depth;
         p.integrator = rr.integrator;
+        p.tonemap = rr.tonemap;
         p.accumulate = PTC_ACCUM_RUNNING_MEAN;
         detail::check(ptc_film_set_sample_count(rr.film, rr.sample_count), "draw_frame");
         detail::check(ptc_render(context.handle, rr.scene, rr.film, &camera, &p), "draw_frame");

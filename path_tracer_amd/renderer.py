@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libptcore.so")
 
 KIND_DIFFUSE, KIND_SPECULAR, KIND_EMISSIVE, KIND_DIELECTRIC = 0, 1, 2, 3
+TONEMAP_PBR_NEUTRAL, TONEMAP_ACES = 0, 1
 INTEGRATOR_MEGAKERNEL, INTEGRATOR_WAVEFRONT, INTEGRATOR_STREAM = 0, 1, 2
 ACCUM_RUNNING_MEAN, ACCUM_SUM = 0, 1
 NO_HIT = 0xFFFFFFFF
@@ -103,7 +104,7 @@ class RenderParams(C.Structure):
                 ("max_depth", C.c_uint32), ("tmax", C.c_float),
                 ("integrator", C.c_uint32), ("accumulate", C.c_uint32),
                 ("instrument", C.c_uint32), ("wavefront_bounces", C.c_uint32),
-                ("reserved", C.c_uint32 * 2)]
+                ("tonemap", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
 
 class Stats(C.Structure):
@@ -466,6 +467,7 @@ class RenderResources:
         self.accumulate = ACCUM_RUNNING_MEAN
         self.instrument = False
         self.wavefront_bounces = 0  # 0 = library default
+        self.tonemap = TONEMAP_PBR_NEUTRAL  # the one the reference compiles in (shader.rgen:218-219)
 
     @property
     def sample_count(self) -> int:
@@ -488,6 +490,7 @@ class RenderResources:
         p.accumulate = self.accumulate
         p.instrument = int(self.instrument)
         p.wavefront_bounces = self.wavefront_bounces
+        p.tonemap = self.tonemap
         _check(lib().ptc_render(self.ctx.handle, self.scene.handle, self.film, C.byref(camera),
                                 C.byref(p)))
 

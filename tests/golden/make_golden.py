@@ -116,7 +116,9 @@ def main():
     tm = []
     for rgb in [(0, 0, 0), (0.05, 0.05, 0.05), (0.5, 0.4, 0.3), (0.9, 0.8, 0.1), (5, 5, 5), (40, 1, 0.2)]:
         t = O.tonemap(rgb)
-        tm.append({"rgb": hx(rgb), "out": hx(t), "unorm8": [O.unorm8(float(x)) for x in t]})
+        a = O.tonemap(rgb, O.TONEMAP_ACES)
+        tm.append({"rgb": hx(rgb), "out": hx(t), "unorm8": [O.unorm8(float(x)) for x in t],
+                   "aces": hx(a), "aces_unorm8": [O.unorm8(float(x)) for x in a]})
     dump("tonemap.json", {"tonemap": tm,
                           "unorm8": [[f"{np.float32(x).view(np.uint32):08x}", O.unorm8(float(np.float32(x)))]
                                      for x in [-1.0, 0.0, 0.5 / 255, 1.5 / 255, 2.5 / 255, 0.5, 1.0, 2.0, float("nan")]]})

@@ -126,6 +126,34 @@ def test_render_bit_exact(scene_pair, ctx, oracle, spf, n_frames, integrator):
     rr.close()
 
 
+def test_aces_tone_map_bit_exact(ctx, oracle):
+    """The alternative tone map of shader.rgen:107-135: same accumulator, RGBA8
+    target identical to the oracle's, also through ptc_film_resolve."""
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(ctx, sc)
+    orc = oracle.Scene(*sc.oracle_args())
+    w, h = 72, 40
+    cam = R.default_camera(w, h)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.max_depth = 6
+    ref = {t: orc.render(oracle.make_push(cam.as_dict(), frame=3), w, h, n_frames=3, max_depth=6,
+                         use_bvh=False, tonemap=t) for t in (oracle.TONEMAP_PBR_NEUTRAL, oracle.TONEMAP_ACES)}
+    assert not np.array_equal(ref[0][1], ref[1][1])
+    for integrator in (R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT):
+        rr.integrator, rr.tonemap = integrator, R.TONEMAP_ACES
+        R.reset_render(rr)
+        rr.render(cam, frame=3, n_frames=3)
+        assert np.array_equal(_bits(rr.read_accum()), _bits(ref[1][0]))
+        assert np.array_equal(rr.read_rgba8(), ref[1][1])
+        rr.resolve(sum_mode=False)
+        assert np.array_equal(rr.read_rgba8(), ref[1][1])
+    rr.tonemap = 7
+    with pytest.raises(R.PtcError, match="unknown tonemap"):
+        rr.render(cam, frame=0)
+    rr.close()
+    dev.close()
+
+
 def test_ray_and_path_counters(ctx, oracle):
     sc = scenes.cornell_box()
     dev = R.DeviceScene(ctx, sc)

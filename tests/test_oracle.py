@@ -160,6 +160,9 @@ def test_tonemap_golden_and_unorm8(oracle):
         t = oracle.tonemap(unhx(c["rgb"]).view(np.float32))
         assert np.array_equal(bits(t), unhx(c["out"]))
         assert [oracle.unorm8(float(x)) for x in t] == c["unorm8"]
+        a = oracle.tonemap(unhx(c["rgb"]).view(np.float32), oracle.TONEMAP_ACES)
+        assert np.array_equal(a.view(np.uint32), unhx(c["aces"]))
+        assert [oracle.unorm8(float(x)) for x in a] == c["aces_unorm8"]
     for hexbits, expect in g["unorm8"]:
         x = np.array([int(hexbits, 16)], np.uint32).view(np.float32)[0]
         assert oracle.unorm8(float(x)) == expect
@@ -168,6 +171,13 @@ def test_tonemap_golden_and_unorm8(oracle):
     assert oracle.unorm8(-3.0) == 0 and oracle.unorm8(7.0) == 255 and oracle.unorm8(float("nan")) == 0
     # below the compression knee the map is x - offset(x)
     assert np.allclose(oracle.tonemap((0.5, 0.5, 0.5)), 0.46)
+    # ACES (shader.rgen:107-135) against a float64 evaluation of the same formula
+    inp = np.array([[0.59719, 0.35458, 0.04823], [0.07600, 0.90834, 0.01566], [0.02840, 0.13383, 0.83777]])
+    outp = np.array([[1.60475, -0.53108, -0.07367], [-0.10208, 1.10813, -0.00605], [-0.00327, -0.07276, 1.07602]])
+    for rgb in [(0.0, 0.0, 0.0), (0.18, 0.18, 0.18), (1.0, 0.5, 0.25), (4.0, 9.0, 0.01), (1e4, 1e4, 1e4)]:
+        v = inp @ np.array(rgb)
+        want = np.clip(outp @ ((v * (v + 0.0245786) - 0.000090537) / (v * (0.983729 * v + 0.4329510) + 0.238081)), 0, 1)
+        assert np.allclose(oracle.tonemap(rgb, oracle.TONEMAP_ACES), want, atol=2e-6)
 
 
 def test_portable_math_close_to_libm(oracle):
