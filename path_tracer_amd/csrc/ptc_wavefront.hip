@@ -163,9 +163,30 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
             finish_path(B, pid, ps.radiance, ps.rng);
         }
     }
-    const uint32_t slot = queue_append(alive, &B.counts[1]);
+    // One atomic per block (the four waves' counts are combined in LDS): with
+    // one per wave, a scene where most camera paths survive is bound by the
+    // rate at which the L2 can add to that one address.
+    __shared__ uint32_t s_alive[kBlock / 64];
+    __shared__ uint32_t s_base;
+    const unsigned long long alive_mask = __ballot(alive);
+    if (lane == 0u)
+    {
+        s_alive[wave] = (uint32_t)__builtin_popcountll(alive_mask);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u)
+    {
+        const uint32_t total = s_alive[0] + s_alive[1] + s_alive[2] + s_alive[3];
+        s_base = total != 0u ? atomicAdd(&B.counts[1], total) : 0u;
+    }
+    __syncthreads();
     if (alive)
     {
+        uint32_t slot = s_base + (uint32_t)__builtin_popcountll(alive_mask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w)
+        {
+            slot += s_alive[w];
+        }
         store_state(B.q[1], slot, ps, pid);
     }
 }
@@ -258,6 +279,9 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     constexpr uint32_t kIdle = 0u, kTrav = 1u, kShade = 2u;
     constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 16u; // lanes that must want a phase before it runs
     uint32_t mode = kIdle;
+    constexpr uint32_t kChunk = 128u; // work items a wave reserves per atomic
+    uint32_t chunk_next = 0u, chunk_end = 0u; // this wave's reserved items not handed out yet
+    bool queue_done = n == 0u;                // nothing left to reserve beyond chunk_end
     bool exhausted = n == 0u;
     PathState ps = camera_path(F, 0u, 0u, 0u);
     uint32_t pid = 0, bounce = 0, rays = 0;
@@ -275,15 +299,30 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
         const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
         if (!exhausted && n_need != 0u && (n_need >= kFetchMin || trav == 0ull))
         {
-            const uint32_t leader = (uint32_t)__builtin_ctzll(need);
-            uint32_t base = 0;
-            if (lane == leader)
+            // Work items come out of a chunk the wave reserved with one atomic;
+            // the next chunk is reserved when this one is used up. (Every wave of
+            // the chip adding to one address serialises in L2 at several ns per
+            // atomic: one atomic per pull would bound the whole kernel.) A pull
+            // that the rest of the chunk cannot serve fully leaves the other
+            // lanes idle until the next pull.
+            if (chunk_next == chunk_end)
             {
-                base = atomicAdd(head, n_need);
+                const uint32_t leader = (uint32_t)__builtin_ctzll(need);
+                uint32_t fresh = 0;
+                if (lane == leader)
+                {
+                    fresh = atomicAdd(head, kChunk);
+                }
+                fresh = __shfl(fresh, (int)leader, 64);
+                chunk_next = fresh < n ? fresh : n;
+                chunk_end = fresh + kChunk < n ? fresh + kChunk : n;
+                queue_done = fresh + kChunk >= n;
             }
-            base = __shfl(base, (int)leader, 64);
-            const uint32_t i = base + (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
-            bool got = mode == kIdle && i < n;
+            const uint32_t avail = chunk_end - chunk_next;
+            const uint32_t rank = (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+            const uint32_t i = chunk_next + rank;
+            bool got = mode == kIdle && rank < avail;
+            chunk_next += n_need < avail ? n_need : avail;
             if (got && kCamera)
             {
                 const uint32_t tile_k = i >> 6, l = i & 63u;
@@ -317,7 +356,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 mode = kTrav;
                 ++rays;
             }
-            exhausted = base + n_need >= n; // wave-uniform: base and n_need are
+            exhausted = queue_done && chunk_next == chunk_end; // wave-uniform
         }
         // ---- shade lanes whose traversal is complete
         const unsigned long long shade = __ballot(mode == kShade);
