@@ -76,10 +76,9 @@ k_flatten(const DInstance *__restrict__ inst, uint32_t n_inst,
           uint32_t n_flat, float4 *__restrict__ tri_tmp, float4 *__restrict__ box_lo,
           float4 *__restrict__ box_hi, uint32_t *__restrict__ bounds)
 {
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
     float lx = INFINITY, ly = INFINITY, lz = INFINITY;
     float hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
-    if (g < n_flat)
+    for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < n_flat; g += gridDim.x * kBlock)
     {
         uint32_t lo = 0, hi = n_inst - 1;
         while (lo < hi)
@@ -105,22 +104,51 @@ k_flatten(const DInstance *__restrict__ inst, uint32_t n_inst,
         tri_tmp[3u * (size_t)g + 0] = make_float4(a.x, a.y, a.z, __uint_as_float(lo));
         tri_tmp[3u * (size_t)g + 1] = make_float4(e1.x, e1.y, e1.z, __uint_as_float(prim));
         tri_tmp[3u * (size_t)g + 2] = make_float4(e2.x, e2.y, e2.z, __uint_as_float(g));
-        lx = fmin_(a.x, fmin_(b.x, c.x));
-        ly = fmin_(a.y, fmin_(b.y, c.y));
-        lz = fmin_(a.z, fmin_(b.z, c.z));
-        hx = fmax_(a.x, fmax_(b.x, c.x));
-        hy = fmax_(a.y, fmax_(b.y, c.y));
-        hz = fmax_(a.z, fmax_(b.z, c.z));
-        box_lo[g] = make_float4(lx, ly, lz, 0.0f);
-        box_hi[g] = make_float4(hx, hy, hz, 0.0f);
+        const float tlx = fmin_(a.x, fmin_(b.x, c.x)), tly = fmin_(a.y, fmin_(b.y, c.y));
+        const float tlz = fmin_(a.z, fmin_(b.z, c.z)), thx = fmax_(a.x, fmax_(b.x, c.x));
+        const float thy = fmax_(a.y, fmax_(b.y, c.y)), thz = fmax_(a.z, fmax_(b.z, c.z));
+        box_lo[g] = make_float4(tlx, tly, tlz, 0.0f);
+        box_hi[g] = make_float4(thx, thy, thz, 0.0f);
+        lx = fmin_(lx, tlx);
+        ly = fmin_(ly, tly);
+        lz = fmin_(lz, tlz);
+        hx = fmax_(hx, thx);
+        hy = fmax_(hy, thy);
+        hz = fmax_(hz, thz);
     }
+    // scene bounds: wave reduction, then the block's waves through LDS, then six
+    // atomics per block (a bounded number of blocks, see the launch)
+    __shared__ float s_red[6][kBlock / 64];
     lx = wave_min(lx);
     ly = wave_min(ly);
     lz = wave_min(lz);
     hx = wave_max(hx);
     hy = wave_max(hy);
     hz = wave_max(hz);
-    if ((threadIdx.x & 63) == 0 && lx <= hx)
+    if ((threadIdx.x & 63) == 0)
+    {
+        const int wv = threadIdx.x >> 6;
+        s_red[0][wv] = lx;
+        s_red[1][wv] = ly;
+        s_red[2][wv] = lz;
+        s_red[3][wv] = hx;
+        s_red[4][wv] = hy;
+        s_red[5][wv] = hz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        for (int wv = 1; wv < kBlock / 64; ++wv)
+        {
+            lx = fmin_(lx, s_red[0][wv]);
+            ly = fmin_(ly, s_red[1][wv]);
+            lz = fmin_(lz, s_red[2][wv]);
+            hx = fmax_(hx, s_red[3][wv]);
+            hy = fmax_(hy, s_red[4][wv]);
+            hz = fmax_(hz, s_red[5][wv]);
+        }
+    }
+    if (threadIdx.x == 0 && lx <= hx)
     {
         atomicMin(&bounds[0], f2ord(lx));
         atomicMin(&bounds[1], f2ord(ly));
@@ -337,6 +365,127 @@ k_merge_emit(uint32_t n, uint32_t n_leaves, uint32_t next_node, const int *__res
         out_id[pos] = in_id[i];
         out_lo[pos] = in_lo[i];
         out_hi[pos] = in_hi[i];
+    }
+}
+
+// The last clustering rounds in one launch. Once the clusters fit one block
+// the per-round work is a few microseconds, and a round of the general path
+// (three kernels, a device scan and a host read-back of the new count) costs
+// two orders of magnitude more. One block keeps the clusters in LDS and runs
+// the same round — nearest neighbour within the radius, mutual pairs merge,
+// survivors compact in order — until one cluster is left, producing exactly
+// the tree the general path would. totals[1] receives the next free node id.
+constexpr int kTailMax = 512;
+
+__global__ void __launch_bounds__(kTailMax)
+k_ploc_tail(uint32_t n, uint32_t n_leaves, uint32_t next_node, int radius,
+            const uint32_t *__restrict__ in_id, const float4 *__restrict__ in_lo,
+            const float4 *__restrict__ in_hi, float4 *__restrict__ node_lo,
+            float4 *__restrict__ node_hi, uint2 *__restrict__ node_lr, uint32_t *__restrict__ totals)
+{
+    __shared__ float4 s_lo[2][kTailMax];
+    __shared__ float4 s_hi[2][kTailMax];
+    __shared__ uint32_t s_id[2][kTailMax];
+    __shared__ int s_nn[kTailMax];
+    __shared__ uint32_t s_scan[2][kTailMax]; // (merges << 16) | survivors, inclusive
+    const uint32_t i = threadIdx.x;
+    if (i < n)
+    {
+        s_lo[0][i] = in_lo[i];
+        s_hi[0][i] = in_hi[i];
+        s_id[0][i] = in_id[i];
+    }
+    int cur = 0;
+    __syncthreads();
+    while (n > 1u)
+    {
+        if (i < n)
+        {
+            const float4 mlo = s_lo[cur][i], mhi = s_hi[cur][i];
+            float best = INFINITY;
+            int best_j = -1;
+            for (int off = -radius; off <= radius; ++off)
+            {
+                const int j = (int)i + off;
+                if (off == 0 || j < 0 || j >= (int)n)
+                {
+                    continue;
+                }
+                const float a = merged_half_area(mlo, mhi, s_lo[cur][j], s_hi[cur][j]);
+                if (a < best)
+                {
+                    best = a;
+                    best_j = j;
+                }
+            }
+            s_nn[i] = best_j;
+        }
+        __syncthreads();
+        bool merge = false, valid = false;
+        int j = -1;
+        if (i < n)
+        {
+            j = s_nn[i];
+            const bool mutual = j >= 0 && s_nn[j] == (int)i;
+            merge = mutual && (int)i < j;
+            valid = !mutual || merge;
+        }
+        const uint32_t mine = ((merge ? 1u : 0u) << 16) | (valid ? 1u : 0u);
+        int sb = 0;
+        s_scan[0][i] = mine;
+        __syncthreads();
+        for (uint32_t step = 1; step < (uint32_t)kTailMax; step <<= 1)
+        {
+            const uint32_t v = s_scan[sb][i] + (i >= step ? s_scan[sb][i - step] : 0u);
+            s_scan[sb ^ 1][i] = v;
+            sb ^= 1;
+            __syncthreads();
+        }
+        const uint32_t incl = s_scan[sb][i], total = s_scan[sb][kTailMax - 1];
+        const uint32_t excl = incl - mine;
+        if (valid)
+        {
+            const uint32_t pos = excl & 0xffffu;
+            if (merge)
+            {
+                const float4 alo = s_lo[cur][i], ahi = s_hi[cur][i], blo = s_lo[cur][j], bhi = s_hi[cur][j];
+                const uint32_t id = next_node + (excl >> 16);
+                float4 lo, hi;
+                lo.x = fmin_(alo.x, blo.x);
+                lo.y = fmin_(alo.y, blo.y);
+                lo.z = fmin_(alo.z, blo.z);
+                hi.x = fmax_(ahi.x, bhi.x);
+                hi.y = fmax_(ahi.y, bhi.y);
+                hi.z = fmax_(ahi.z, bhi.z);
+                lo.w = __uint_as_float(__float_as_uint(alo.w) + __float_as_uint(blo.w));
+                hi.w = 0.0f;
+                node_lo[id] = lo;
+                node_hi[id] = hi;
+                node_lr[id - n_leaves] = make_uint2(s_id[cur][i], s_id[cur][j]);
+                s_id[cur ^ 1][pos] = id;
+                s_lo[cur ^ 1][pos] = lo;
+                s_hi[cur ^ 1][pos] = hi;
+            }
+            else
+            {
+                s_id[cur ^ 1][pos] = s_id[cur][i];
+                s_lo[cur ^ 1][pos] = s_lo[cur][i];
+                s_hi[cur ^ 1][pos] = s_hi[cur][i];
+            }
+        }
+        __syncthreads();
+        if ((total >> 16) == 0u)
+        {
+            break; // no mutual pair: cannot happen for n > 1, but never spin
+        }
+        next_node += total >> 16;
+        n = total & 0xffffu;
+        cur ^= 1;
+    }
+    if (i == 0u)
+    {
+        totals[0] = n;
+        totals[1] = next_node;
     }
 }
 
@@ -677,26 +826,58 @@ k_wide_emit(uint32_t level_start, uint32_t level_end, uint32_t n_leaves, uint32_
     out[2] = w2;
     out[3] = w3;
     out[4] = w4;
-    atomicAdd(cost_sum, (double)cost);
+    // one atomic per wave: adds of every thread to the one address would
+    // serialise in L2 (about 10 ns each) and dominate large builds
+    unsigned long long active = __ballot(1);
+    const int first = __builtin_ctzll(active);
+    double wave_cost = 0.0;
+    while (active)
+    {
+        wave_cost += __shfl((double)cost, __builtin_ctzll(active), 64);
+        active &= active - 1ull;
+    }
+    if ((int)(threadIdx.x & 63u) == first)
+    {
+        atomicAdd(cost_sum, wave_cost);
+    }
 }
 
+// Build scratch: one device allocation carved up in order (dozens of separate
+// hipMalloc / hipFree calls cost more than the kernels of a small build);
+// requests beyond the estimate fall back to allocations of their own.
 struct TempPool
 {
-    std::vector<void *> ptrs;
+    char *arena = nullptr;
+    size_t capacity = 0, used = 0;
+    std::vector<void *> extra;
     ~TempPool()
     {
-        for (void *p : ptrs)
+        (void)hipFree(arena);
+        for (void *p : extra)
         {
             (void)hipFree(p);
         }
     }
+    hipError_t reserve(size_t bytes)
+    {
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&arena), bytes);
+        capacity = e == hipSuccess ? bytes : 0;
+        return e;
+    }
     template <typename T> hipError_t alloc(T **out, size_t count)
     {
+        const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+        if (used + bytes <= capacity)
+        {
+            *out = reinterpret_cast<T *>(arena + used);
+            used += bytes;
+            return hipSuccess;
+        }
         void *p = nullptr;
-        const hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        const hipError_t e = hipMalloc(&p, bytes);
         if (e == hipSuccess)
         {
-            ptrs.push_back(p);
+            extra.push_back(p);
             *out = static_cast<T *>(p);
         }
         return e;
@@ -716,6 +897,8 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
     hipStream_t st = ctx->stream;
     const int radius = (int)std::min<uint32_t>(search_radius ? search_radius : 16u, kMaxRadius);
     TempPool pool;
+    // about 390 bytes of scratch per triangle, plus the sort's and the scan's own
+    PTC_HIP_CHECK(pool.reserve((size_t)n * 448 + (64u << 20)));
 
     // outputs
     const size_t node_cap = std::max<size_t>(n, 1);
@@ -772,7 +955,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
         const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
         PTC_HIP_CHECK(hipMemcpyAsync(bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, st));
 
-        k_flatten<<<blocks_for(n), kBlock, 0, st>>>(scene->d_instances, (uint32_t)instances.size(),
+        k_flatten<<<std::min<uint32_t>(blocks_for(n), 2048u), kBlock, 0, st>>>(scene->d_instances, (uint32_t)instances.size(),
                                                    scene->d_positions, scene->d_indices, n, tri_tmp,
                                                    box_lo, box_hi, bounds);
         k_morton<<<blocks_for(n), kBlock, 0, st>>>(n, box_lo, box_hi, bounds, keys_in, vals_in);
@@ -796,7 +979,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
         uint32_t n_cl = n, next_node = n;
         int cur = 0;
         int rounds = 0;
-        while (n_cl > 1)
+        while (n_cl > (uint32_t)kTailMax)
         {
             k_nearest<<<blocks_for(n_cl), kBlock, 0, st>>>(n_cl, radius, cl_lo[cur], cl_hi[cur], nn);
             k_merge_flags<<<blocks_for(n_cl), kBlock, 0, st>>>(n_cl, nn, flags);
@@ -822,6 +1005,20 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
                 set_error("BVH build: too many clustering rounds");
                 return PTC_E_DEVICE;
             }
+        }
+        if (n_cl > 1)
+        {
+            k_ploc_tail<<<1, kTailMax, 0, st>>>(n_cl, n, next_node, radius, cl_id[cur], cl_lo[cur], cl_hi[cur],
+                                                node_lo, node_hi, node_lr, totals);
+            uint32_t h_tot[2];
+            PTC_HIP_CHECK(hipMemcpyAsync(h_tot, totals, sizeof h_tot, hipMemcpyDeviceToHost, st));
+            PTC_HIP_CHECK(hipStreamSynchronize(st));
+            if (h_tot[0] != 1u)
+            {
+                set_error("BVH build: clustering tail made no progress");
+                return PTC_E_DEVICE;
+            }
+            next_node = h_tot[1];
         }
         const uint32_t binary_root = n == 1 ? 0u : next_node - 1u;
 
