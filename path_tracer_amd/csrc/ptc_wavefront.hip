@@ -52,7 +52,14 @@ struct WfBuffers
     uint32_t n_pixels;
 };
 
-// path id = (dispatch * spf + sample) * n_pixels + pixel
+// path id = (dispatch * spf + sample) * n_pixels + pixel. (Keeping the paths of
+// one pixel next to each other instead makes the resolve pass 5x slower and
+// the stores of the primary pass no faster.)
+PTC_DEV uint32_t path_id(const WfBuffers &B, uint32_t pixel, uint32_t k, uint32_t sample)
+{
+    return (k * B.spf + sample) * B.n_pixels + pixel;
+}
+
 PTC_DEV void finish_path(const WfBuffers &B, uint32_t pid, vec3 L, uint32_t rng)
 {
     B.radiance[pid] = make_float4(L.x, L.y, L.z, 1.0f);
@@ -120,6 +127,7 @@ PTC_DEV PathState camera_path(const DFrame &F, uint32_t px, uint32_t py, uint32_
 }
 
 constexpr int kPrimaryLds = 16; // LDS stack entries per lane (two pushes per level)
+template <bool kPixelMajor>
 __global__ void __launch_bounds__(kBlock)
 k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample,
              uint32_t n_disp)
@@ -127,19 +135,44 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
     __shared__ uint2 s_stack[kPrimaryLds * kBlock];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tiles_x = (F.width + 15u) >> 4;
-    // consecutive blocks are the dispatches of one tile, so the blocks resident
-    // at any time (and the queue they fill) stay within a few tiles' geometry
-    // and those tiles form a compact patch: tiles are numbered along a Z-order
-    // curve inside 8x8-tile groups.
-    const uint32_t tile = blockIdx.x / n_disp;
-    const uint32_t k = blockIdx.x % n_disp; // dispatch within this batch
     const uint32_t groups_x = (tiles_x + 7u) >> 3;
-    const uint32_t group = tile >> 6, m = tile & 63u;
-    const uint32_t bx = (group % groups_x) * 8u + ((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u));
-    const uint32_t by = (group / groups_x) * 8u + (((m >> 1) & 1u) | ((m >> 2) & 2u) | ((m >> 3) & 4u));
-    const uint32_t px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const bool inside = px < F.width && py < F.height; // false for all lanes of tiles past the edge
+    uint32_t px, py, k;
+    bool inside;
+    if (kPixelMajor)
+    {
+        // A wave is one pixel, its lanes are 64 dispatches of that pixel: the 64
+        // camera rays differ by the pixel-filter jitter only, so they visit the
+        // same nodes in the same order (node fetches go through the scalar
+        // cache, no lane waits for a longer traversal), and the queue receives
+        // the survivors of one pixel next to each other. Pixels are numbered
+        // along a Z-order curve inside 16x16 tiles, tiles as below.
+        const uint32_t k_groups = (n_disp + 63u) >> 6;
+        const uint32_t q = (blockIdx.x / k_groups) * (kBlock / 64) + wave; // pixel number
+        k = (blockIdx.x % k_groups) * 64u + lane;
+        const uint32_t tile = q >> 8, l = q & 255u;
+        const uint32_t group = tile >> 6, m = tile & 63u;
+        const uint32_t bx = (group % groups_x) * 8u + ((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u));
+        const uint32_t by = (group / groups_x) * 8u + (((m >> 1) & 1u) | ((m >> 2) & 2u) | ((m >> 3) & 4u));
+        px = bx * 16u + ((l & 1u) | ((l >> 1) & 2u) | ((l >> 2) & 4u) | ((l >> 3) & 8u));
+        py = by * 16u + (((l >> 1) & 1u) | ((l >> 2) & 2u) | ((l >> 3) & 4u) | ((l >> 4) & 8u));
+        inside = px < F.width && py < F.height && k < n_disp;
+    }
+    else
+    {
+        // A wave is an 8x8 pixel tile of one dispatch. Consecutive blocks are the
+        // dispatches of one tile, so the blocks resident at any time (and the
+        // queue they fill) stay within a few tiles' geometry, and those tiles
+        // form a compact patch: tiles are numbered along a Z-order curve inside
+        // 8x8-tile groups.
+        const uint32_t tile = blockIdx.x / n_disp;
+        k = blockIdx.x % n_disp; // dispatch within this batch
+        const uint32_t group = tile >> 6, m = tile & 63u;
+        const uint32_t bx = (group % groups_x) * 8u + ((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u));
+        const uint32_t by = (group / groups_x) * 8u + (((m >> 1) & 1u) | ((m >> 2) & 2u) | ((m >> 3) & 4u));
+        px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+        py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+        inside = px < F.width && py < F.height; // false for all lanes of tiles past the edge
+    }
     bool alive = false;
     PathState ps = camera_path(F, 0u, 0u, 0u);
     uint32_t pid = 0;
@@ -147,7 +180,7 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
     {
         const uint32_t pixel_index = py * F.width + px;
         const uint32_t n_pixels = F.width * F.height;
-        pid = (k * B.spf + sample) * n_pixels + pixel_index;
+        pid = path_id(B, pixel_index, k, sample);
         ps = camera_path(F, px, py,
                          sample == 0u ? seed_(pixel_index, frame_first + (k_first + k) * F.frame_stride)
                                       : B.carry[k * n_pixels + pixel_index]);
@@ -335,7 +368,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 {
                     const uint32_t pixel_index = py * F.width + px;
                     sample = 0u;
-                    pid = (k * B.spf) * B.n_pixels + pixel_index;
+                    pid = path_id(B, pixel_index, k, 0u);
                     ps = camera_path(F, px, py,
                                      seed_(pixel_index, F.global_frame_count + (k_first + k) * F.frame_stride));
                     bounce = 0u;
@@ -609,7 +642,18 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             PTC_HIP_CHECK(hipMemsetAsync(B.counts, 0, n_counts * 4, st));
             {
                 PhaseTimer timer(ctx, PTC_PHASE_PRIMARY);
-                k_wf_primary<<<tiles * nb, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0, s, nb);
+                if (nb >= 32u)
+                {
+                    // one wave per pixel, 64 dispatches per wave
+                    const uint32_t pixel_blocks = tiles * 256u / (kBlock / 64);
+                    k_wf_primary<true><<<pixel_blocks * ((nb + 63u) / 64u), kBlock, 0, st>>>(
+                        scene->d, F0, B, F0.global_frame_count, k0, s, nb);
+                }
+                else
+                {
+                    k_wf_primary<false><<<tiles * nb, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0,
+                                                                      s, nb);
+                }
             }
             const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_paths + kBlock - 1) / kBlock);
             // bounces [1, drain_b) as trace / shade launch pairs over compacted queues
