@@ -126,7 +126,7 @@ PTC_DEV PathState camera_path(const DFrame &F, uint32_t px, uint32_t py, uint32_
     return ps;
 }
 
-constexpr int kPrimaryLds = 16; // LDS stack entries per lane (two pushes per level)
+constexpr int kPrimaryLds = 8; // LDS stack entries per lane: 16 KB per block, so registers (not LDS) set the occupancy
 template <bool kPixelMajor>
 __global__ void __launch_bounds__(kBlock)
 k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample,
