@@ -233,8 +233,8 @@ k_wf_trace(DScene S, float tmax, WfState q, float4 *__restrict__ hit, uint2 *__r
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
     {
         const float4 a = q.a[i], b = q.b[i];
-        const Hit h = trace_closest<false>(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), tmax,
-                                           s_stack + threadIdx.x, kBlock, nullptr);
+        const Hit h = trace_closest_interleaved(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), tmax,
+                                                s_stack + threadIdx.x, kBlock);
         hit[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.flat));
         hit_ids[i] = make_uint2(h.instance, h.primitive);
     }
