@@ -556,26 +556,21 @@ PTC_DEV float ubyte_f(uint32_t w, int i)
 PTC_DEV bool mt_test(vec3 o, vec3 d, vec3 v0, vec3 e1, vec3 e2, float tmax, float &t,
                      float &u, float &v)
 {
+    // straight-line code (det == 0 is part of the final condition, not an early
+    // exit): a branch here makes the compiler sink part of the triangle load
+    // below it, which costs a second memory round trip per test
     const vec3 p = cross(d, e2);
     const float det = dot(e1, p);
-    if (det == 0.0f)
-    {
-        return false;
-    }
     const float inv = 1.0f / det;
     const vec3 tv = o - v0;
     const float uu = dot(tv, p) * inv;
     const vec3 q = cross(tv, e1);
     const float vv = dot(d, q) * inv;
     const float tt = dot(e2, q) * inv;
-    if (uu >= 0.0f && vv >= 0.0f && (uu + vv) <= 1.0f && tt > 0.0f && tt < tmax)
-    {
-        t = tt;
-        u = uu;
-        v = vv;
-        return true;
-    }
-    return false;
+    t = tt;
+    u = uu;
+    v = vv;
+    return det != 0.0f && uu >= 0.0f && vv >= 0.0f && (uu + vv) <= 1.0f && tt > 0.0f && tt < tmax;
 }
 
 // Per-ray constants of a traversal.
@@ -740,20 +735,19 @@ PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t 
 // best hit in (t, flat) order.
 PTC_DEV void tri_eval(const float4 a, const float4 b, const float4 c, const RayCtx &R, Hit &best)
 {
-    float t, u, v;
-    if (mt_test(R.o, R.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), R.tmax, t, u, v))
-    {
-        const uint32_t flat = __float_as_uint(c.w);
-        if (t < best.t || (t == best.t && flat < best.flat))
-        {
-            best.t = t;
-            best.u = u;
-            best.v = v;
-            best.flat = flat;
-            best.instance = __float_as_uint(a.w);
-            best.primitive = __float_as_uint(b.w);
-        }
-    }
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+    const bool hit = mt_test(R.o, R.d, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), R.tmax, t, u, v);
+    // selects, not a branch: every word of the record is then used on every
+    // path, which keeps the record at three 16-byte loads (behind a branch the
+    // compiler splits the ids off into loads of their own)
+    const uint32_t flat = __float_as_uint(c.w);
+    const bool better = hit && (t < best.t || (t == best.t && flat < best.flat));
+    best.t = better ? t : best.t;
+    best.u = better ? u : best.u;
+    best.v = better ? v : best.v;
+    best.flat = better ? flat : best.flat;
+    best.instance = better ? __float_as_uint(a.w) : best.instance;
+    best.primitive = better ? __float_as_uint(b.w) : best.primitive;
 }
 
 PTC_DEV void tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index, Hit &best)
