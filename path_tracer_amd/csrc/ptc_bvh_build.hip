@@ -898,7 +898,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
     const int radius = (int)std::min<uint32_t>(search_radius ? search_radius : 16u, kMaxRadius);
     TempPool pool;
     // about 390 bytes of scratch per triangle, plus the sort's and the scan's own
-    PTC_HIP_CHECK(pool.reserve((size_t)n * 448 + (64u << 20)));
+    PTC_HIP_CHECK(pool.reserve((size_t)n * 480 + (1u << 20)));
 
     // outputs
     const size_t node_cap = std::max<size_t>(n, 1);

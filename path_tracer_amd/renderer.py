@@ -463,7 +463,7 @@ class RenderResources:
         # knobs the reference hard-codes in shader.rgen
         self.max_depth = 32
         self.tmax = 10000.0
-        self.integrator = INTEGRATOR_MEGAKERNEL
+        self.integrator = INTEGRATOR_WAVEFRONT  # like the C++ mirror; all integrators give the same film
         self.accumulate = ACCUM_RUNNING_MEAN
         self.instrument = False
         self.wavefront_bounces = 0  # 0 = library default
