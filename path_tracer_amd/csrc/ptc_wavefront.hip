@@ -327,10 +327,50 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     for (;;)
     {
         const unsigned long long trav = __ballot(mode == kTrav);
-        // ---- pull new paths for idle lanes
+        bool start = false; // this lane starts tracing a new ray in this iteration
+        // ---- shade lanes whose traversal is complete
+        const unsigned long long shade = __ballot(mode == kShade);
+        const uint32_t n_shade = (uint32_t)__builtin_popcountll(shade);
+        const bool run_shade = n_shade != 0u && (n_shade >= kShadeMin || trav == 0ull);
+        if (run_shade)
+        {
+            if (mode == kShade)
+            {
+                const bool alive = path_bounce(S, best, ps) && (bounce + 1u) < max_depth;
+                ++bounce;
+                if (alive)
+                {
+                    start = true;
+                }
+                else if (kCamera)
+                {
+                    B.radiance[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, 1.0f);
+                    if (++sample < B.spf)
+                    {
+                        // next sample of the same dispatch continues the RNG stream
+                        pid += B.n_pixels;
+                        ps = camera_path(F, px, py, ps.rng);
+                        bounce = 0u;
+                        start = true;
+                    }
+                    else
+                    {
+                        mode = kIdle;
+                    }
+                }
+                else
+                {
+                    finish_path(B, pid, ps.radiance, ps.rng);
+                    mode = kIdle;
+                }
+            }
+        }
+        // ---- pull new paths for idle lanes: when enough are idle, and right
+        // after a shading phase (the lanes whose paths just ended restart together
+        // with the lanes whose paths continue, instead of waiting for company)
         const unsigned long long need = __ballot(mode == kIdle);
         const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
-        if (!exhausted && n_need != 0u && (n_need >= kFetchMin || trav == 0ull))
+        if (!exhausted && n_need != 0u && (n_need >= kFetchMin || run_shade || trav == 0ull))
         {
             // Work items come out of a chunk the wave reserved with one atomic;
             // the next chunk is reserved when this one is used up. (Every wave of
@@ -379,65 +419,18 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 pid = load_state(qi, i, ps);
                 bounce = bounce0;
             }
-            if (got)
-            {
-                R = make_ray_ctx(ps.origin, ps.dir, tmax);
-                best = no_hit(tmax);
-                ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
-                tg = make_uint2(0u, 0u);
-                sp = 0;
-                mode = kTrav;
-                ++rays;
-            }
+            start = start || got;
             exhausted = queue_done && chunk_next == chunk_end; // wave-uniform
         }
-        // ---- shade lanes whose traversal is complete
-        const unsigned long long shade = __ballot(mode == kShade);
-        const uint32_t n_shade = (uint32_t)__builtin_popcountll(shade);
-        if (n_shade != 0u && (n_shade >= kShadeMin || __ballot(mode == kTrav) == 0ull))
+        if (start)
         {
-            if (mode == kShade)
-            {
-                const bool alive = path_bounce(S, best, ps) && (bounce + 1u) < max_depth;
-                ++bounce;
-                if (alive)
-                {
-                    R = make_ray_ctx(ps.origin, ps.dir, tmax);
-                    best = no_hit(tmax);
-                    ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
-                    tg = make_uint2(0u, 0u);
-                    sp = 0;
-                    mode = kTrav;
-                    ++rays;
-                }
-                else if (kCamera)
-                {
-                    B.radiance[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, 1.0f);
-                    if (++sample < B.spf)
-                    {
-                        // next sample of the same dispatch continues the RNG stream
-                        pid += B.n_pixels;
-                        ps = camera_path(F, px, py, ps.rng);
-                        bounce = 0u;
-                        R = make_ray_ctx(ps.origin, ps.dir, tmax);
-                        best = no_hit(tmax);
-                        ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
-                        tg = make_uint2(0u, 0u);
-                        sp = 0;
-                        mode = kTrav;
-                        ++rays;
-                    }
-                    else
-                    {
-                        mode = kIdle;
-                    }
-                }
-                else
-                {
-                    finish_path(B, pid, ps.radiance, ps.rng);
-                    mode = kIdle;
-                }
-            }
+            R = make_ray_ctx(ps.origin, ps.dir, tmax);
+            best = no_hit(tmax);
+            ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
+            tg = make_uint2(0u, 0u);
+            sp = 0;
+            mode = kTrav;
+            ++rays;
         }
         if (exhausted && __ballot(mode != kIdle) == 0ull)
         {
