@@ -628,11 +628,14 @@ PTC_DEV uint32_t next_child(uint2 &ng, uint32_t octinv)
 // Tests the 8 child boxes of one wide node (its five 16-byte words w0..w4)
 // against the ray; yields the group of hit internal children and the group of
 // triangles of hit leaf slots.
+// (octinv is passed beside R: a caller that knows the node words and the octant
+// to be the same in every lane hands in wave-uniform values, and everything that
+// depends on them alone — exponent decode, near / far plane selection, the hit
+// bits of each slot — is then computed once on the scalar unit.)
 PTC_DEV void node_eval(const uint4 w0, const uint4 w1, const uint4 w2, const uint4 w3, const uint4 w4,
-                       const RayCtx &R, float best_t, uint2 &ng, uint2 &tg)
+                       const RayCtx &R, uint32_t octinv, float best_t, uint2 &ng, uint2 &tg)
 {
     const uint32_t imask = w0.w >> 24;
-    const uint32_t octinv = R.octinv;
     const bool negx = !(octinv & 1u), negy = !(octinv & 2u), negz = !(octinv & 4u);
     const float sx = __uint_as_float((w0.w & 0xffu) << 23) * R.idx;
     const float sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * R.idy;
@@ -702,9 +705,9 @@ PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t 
                        uint2 &tg)
 {
     // When every active lane of the wave visits the same node (the root always;
-    // whole tiles of camera rays often), fetch it once through the scalar cache
-    // instead of 64 times through the vector memory path.
-    uint4 w0, w1, w2, w3, w4;
+    // camera rays of one pixel nearly always), fetch it once through the scalar
+    // cache instead of 64 times through the vector memory path; if the lanes also
+    // share the ray octant, the per-node part of the test runs on the scalar unit.
     const uint32_t first_idx = __builtin_amdgcn_readfirstlane(node_idx);
     if (__builtin_amdgcn_ballot_w64(node_idx != first_idx) == 0ull)
     {
@@ -713,22 +716,25 @@ PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t 
         typedef const __attribute__((address_space(4))) u32x4 *scalar_ptr;
         const scalar_ptr N = (scalar_ptr)(uintptr_t)(S.nodes + 5u * (size_t)first_idx);
         const u32x4 s0 = N[0], s1 = N[1], s2 = N[2], s3 = N[3], s4 = N[4];
-        w0 = make_uint4(s0.x, s0.y, s0.z, s0.w);
-        w1 = make_uint4(s1.x, s1.y, s1.z, s1.w);
-        w2 = make_uint4(s2.x, s2.y, s2.z, s2.w);
-        w3 = make_uint4(s3.x, s3.y, s3.z, s3.w);
-        w4 = make_uint4(s4.x, s4.y, s4.z, s4.w);
+        const uint4 w0 = make_uint4(s0.x, s0.y, s0.z, s0.w), w1 = make_uint4(s1.x, s1.y, s1.z, s1.w);
+        const uint4 w2 = make_uint4(s2.x, s2.y, s2.z, s2.w), w3 = make_uint4(s3.x, s3.y, s3.z, s3.w);
+        const uint4 w4 = make_uint4(s4.x, s4.y, s4.z, s4.w);
+        const uint32_t first_oct = __builtin_amdgcn_readfirstlane(R.octinv);
+        if (__builtin_amdgcn_ballot_w64(R.octinv != first_oct) == 0ull)
+        {
+            node_eval(w0, w1, w2, w3, w4, R, first_oct, best_t, ng, tg);
+        }
+        else
+        {
+            node_eval(w0, w1, w2, w3, w4, R, R.octinv, best_t, ng, tg);
+        }
     }
     else
     {
         const uint4 *__restrict__ N = S.nodes + 5u * (size_t)node_idx;
-        w0 = N[0];
-        w1 = N[1];
-        w2 = N[2];
-        w3 = N[3];
-        w4 = N[4];
+        const uint4 w0 = N[0], w1 = N[1], w2 = N[2], w3 = N[3], w4 = N[4];
+        node_eval(w0, w1, w2, w3, w4, R, R.octinv, best_t, ng, tg);
     }
-    node_eval(w0, w1, w2, w3, w4, R, best_t, ng, tg);
 }
 
 // Tests one triangle (its three 16-byte words) and keeps it if it beats the
