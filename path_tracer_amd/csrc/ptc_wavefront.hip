@@ -130,7 +130,7 @@ constexpr int kPrimaryLds = 8; // LDS stack entries per lane: 16 KB per block, s
 template <bool kPixelMajor>
 __global__ void __launch_bounds__(kBlock)
 k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample,
-             uint32_t n_disp)
+             uint32_t n_disp, uint32_t lane_bits)
 {
     __shared__ uint2 s_stack[kPrimaryLds * kBlock];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -146,9 +146,12 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
         // cache, no lane waits for a longer traversal), and the queue receives
         // the survivors of one pixel next to each other. Pixels are numbered
         // along a Z-order curve inside 16x16 tiles, tiles as below.
-        const uint32_t k_groups = (n_disp + 63u) >> 6;
-        const uint32_t q = (blockIdx.x / k_groups) * (kBlock / 64) + wave; // pixel number
-        k = (blockIdx.x % k_groups) * 64u + lane;
+        // (With fewer than 64 dispatches a wave takes 2 or 4 neighbouring pixels,
+        // 32 or 16 dispatches each: lane_bits = log2 of the lanes per pixel.)
+        const uint32_t lanes_per_pixel = 1u << lane_bits, pixels_per_block = kBlock >> lane_bits;
+        const uint32_t k_groups = (n_disp + lanes_per_pixel - 1u) >> lane_bits;
+        const uint32_t q = (blockIdx.x / k_groups) * pixels_per_block + (threadIdx.x >> lane_bits); // pixel number
+        k = (blockIdx.x % k_groups) * lanes_per_pixel + (threadIdx.x & (lanes_per_pixel - 1u));
         const uint32_t tile = q >> 8, l = q & 255u;
         const uint32_t group = tile >> 6, m = tile & 63u;
         const uint32_t bx = (group % groups_x) * 8u + ((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u));
@@ -635,17 +638,30 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             PTC_HIP_CHECK(hipMemsetAsync(B.counts, 0, n_counts * 4, st));
             {
                 PhaseTimer timer(ctx, PTC_PHASE_PRIMARY);
-                if (nb >= 32u)
+                // lanes per pixel: 64, 32 or 16, whichever leaves the fewest lanes
+                // without a dispatch (ties go to the wider one)
+                uint32_t lane_bits = 0, best_waste = ~0u;
+                for (uint32_t bits = 6; bits >= 4; --bits)
                 {
-                    // one wave per pixel, 64 dispatches per wave
-                    const uint32_t pixel_blocks = tiles * 256u / (kBlock / 64);
-                    k_wf_primary<true><<<pixel_blocks * ((nb + 63u) / 64u), kBlock, 0, st>>>(
-                        scene->d, F0, B, F0.global_frame_count, k0, s, nb);
+                    const uint32_t groups = (nb + (1u << bits) - 1u) >> bits;
+                    const uint32_t waste = (groups << bits) - nb;
+                    if (waste < best_waste)
+                    {
+                        best_waste = waste;
+                        lane_bits = bits;
+                    }
+                }
+                if (nb >= 16u)
+                {
+                    const uint32_t pixel_blocks = (tiles * 256u) / (kBlock >> lane_bits);
+                    const uint32_t k_groups = (nb + (1u << lane_bits) - 1u) >> lane_bits;
+                    k_wf_primary<true><<<pixel_blocks * k_groups, kBlock, 0, st>>>(
+                        scene->d, F0, B, F0.global_frame_count, k0, s, nb, lane_bits);
                 }
                 else
                 {
                     k_wf_primary<false><<<tiles * nb, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0,
-                                                                      s, nb);
+                                                                      s, nb, 0u);
                 }
             }
             const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_paths + kBlock - 1) / kBlock);
