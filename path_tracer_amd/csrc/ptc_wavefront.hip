@@ -1,23 +1,30 @@
 // Wavefront integrator: the path loop of src/shaders/shader.rgen:60-100 turned
 // inside out. Instead of one lane walking one pixel's path to the end (lanes of
-// a wave then idle while the longest path finishes), every bounce is a pair of
-// launches over a compacted queue of live paths:
+// a wave then idle while the longest path finishes), live paths sit in a
+// compacted queue between bounces:
 //
 //   k_wf_primary  bounce 0, fused: camera ray -> traversal -> material / sky.
 //                 Camera rays are coherent, so fusing costs nothing and saves
-//                 writing 3/4 of the paths (those that end at the sky) to HBM.
-//   k_wf_trace    traversal + Moller-Trumbore for queue slot i -> hit record
-//   k_wf_shade    material / sky, emission, Russian roulette; survivors are
-//                 appended to the next queue with one atomic per wave
-//                 (ballot + popcount prefix), so the next launch runs full waves
+//                 writing the paths that end at the sky (3/4 of them in an
+//                 open scene) to memory. Survivors are appended to the queue.
+//   k_wf_drain    one persistent launch that finishes every queued path: each
+//                 lane is a small state machine (idle / traversing / waiting to
+//                 be shaded) that pulls the next path when its own ends.
 //   k_wf_resolve  folds the per-path radiances of each pixel, in dispatch
 //                 order, into the film exactly as shader.rgen:202-223 does
 //
+// and, for comparison (wavefront_bounces > 0), bounces as launch pairs before
+// the persistent launch takes over:
+//
+//   k_wf_trace    traversal + Moller-Trumbore for queue slot i -> hit record
+//   k_wf_shade    material / sky, emission, Russian roulette; survivors are
+//                 appended to the next queue with one atomic per wave
+//
 // A path is (pixel, dispatch k); its id is k * n_pixels + pixel. Live-path state
-// lives in two ping-pong sets of SoA arrays indexed by queue slot, so every
-// access of the per-bounce kernels is coalesced; only the final radiance is
-// scattered by path id. Each path carries its own RNG state, so results do not
-// depend on queue order and equal the megakernel's bit for bit.
+// lives in SoA arrays indexed by queue slot, so queue reads and writes are
+// coalesced; only the final radiance is scattered by path id. Each path carries
+// its own RNG state, so results do not depend on queue order and equal the
+// megakernel's bit for bit.
 #include "ptc_internal.h"
 
 #include <algorithm>
