@@ -180,7 +180,12 @@ typedef struct ptc_render_params
      * "#else" (shader.rgen:107-135, :220-221). Remembered by the film for
      * ptc_film_resolve(). */
     uint32_t tonemap;
-    uint32_t reserved[1];
+    /* Wavefront / stream integrators: upper bound on the paths in flight, which
+     * sizes the per-context workspace (about 160 bytes per path with the
+     * wavefront integrator, 16 with the stream one). A call with more paths runs
+     * in several batches of whole dispatches. 0 = 2^27 (about 21 GB); at least
+     * one dispatch is always in flight. Does not change results. */
+    uint32_t max_paths_in_flight;
 } ptc_render_params;
 #define PTC_TONEMAP_PBR_NEUTRAL 0u
 #define PTC_TONEMAP_ACES 1u

@@ -76,6 +76,8 @@ DFrame make_frame(const ptc_camera &cam, uint32_t width, uint32_t height)
     F.frame_stride = 1;
     F.samples_per_frame = 1;
     F.tonemap = PTC_TONEMAP_PBR_NEUTRAL;
+    F.wavefront_bounces = 0;
+    F.max_paths_in_flight = 1u << 27;
     return F;
 }
 
@@ -715,6 +717,7 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
     F.tonemap = params->tonemap;
     film->tonemap = params->tonemap;
     F.wavefront_bounces = params->wavefront_bounces;
+    F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : (1u << 27);
     // one event pair per call, kept until ptc_render_times() collects them
     constexpr size_t kMaxTimed = 256;
     if (ctx->ev_used == ctx->ev_pool.size() && ctx->ev_pool.size() < kMaxTimed)

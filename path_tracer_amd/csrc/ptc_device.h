@@ -60,6 +60,7 @@ struct DFrame
     uint32_t accumulate_sum;
     uint32_t tonemap; // PTC_TONEMAP_*
     uint32_t wavefront_bounces; // bounces run as trace / shade launch pairs before the drain launch
+    uint32_t max_paths_in_flight; // workspace bound of the queue-based integrators
 };
 
 struct Hit

@@ -577,9 +577,10 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     const uint32_t n_pixels = F0.width * F0.height;
     const uint32_t spf = F0.samples_per_frame;
     const uint32_t wf_bounces = F0.wavefront_bounces;
-    // dispatches per batch: bounded so the workspace stays bounded (2^27 paths, about 23 GB)
+    // dispatches per batch: bounded so the workspace stays bounded (by default 2^27 paths, about 21 GB)
     const uint32_t max_batch = std::max<uint32_t>(
-        1u, std::min<uint32_t>(F0.n_frames, (1u << 27) / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
+        1u, std::min<uint64_t>(F0.n_frames,
+                               F0.max_paths_in_flight / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
     const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
     const size_t n_counts = (size_t)F0.max_depth + 2;
     // stream mode keeps live paths in registers: only the radiance array is needed

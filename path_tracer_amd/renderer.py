@@ -104,7 +104,7 @@ class RenderParams(C.Structure):
                 ("max_depth", C.c_uint32), ("tmax", C.c_float),
                 ("integrator", C.c_uint32), ("accumulate", C.c_uint32),
                 ("instrument", C.c_uint32), ("wavefront_bounces", C.c_uint32),
-                ("tonemap", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("tonemap", C.c_uint32), ("max_paths_in_flight", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -467,6 +467,7 @@ class RenderResources:
         self.accumulate = ACCUM_RUNNING_MEAN
         self.instrument = False
         self.wavefront_bounces = 0  # 0 = library default
+        self.max_paths_in_flight = 0  # 0 = library default (2^27)
         self.tonemap = TONEMAP_PBR_NEUTRAL  # the one the reference compiles in (shader.rgen:218-219)
 
     @property
@@ -490,6 +491,7 @@ class RenderResources:
         p.accumulate = self.accumulate
         p.instrument = int(self.instrument)
         p.wavefront_bounces = self.wavefront_bounces
+        p.max_paths_in_flight = self.max_paths_in_flight
         p.tonemap = self.tonemap
         _check(lib().ptc_render(self.ctx.handle, self.scene.handle, self.film, C.byref(camera),
                                 C.byref(p)))

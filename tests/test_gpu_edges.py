@@ -1,0 +1,191 @@
+"""Edge cases of the HIP path through the C ABI, each against the CPU oracle:
+empty and degenerate scenes, depth 0 and 1, tiny films, a workspace bound that
+splits one call into several batches, continued films, caller-owned buffers,
+device-resident ray queries, and argument errors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from path_tracer_amd import renderer as R
+from path_tracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+INTEGRATORS = [R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _render_all(ctx, oracle, sc, w, h, n_frames, max_depth, spf=1, **kw):
+    dev = R.DeviceScene(ctx, sc)
+    orc = oracle.Scene(*sc.oracle_args())
+    cam = R.default_camera(w, h)
+    push = oracle.make_push(cam.as_dict(), frame=1, sample_count=0, samples_per_frame=spf)
+    ref_acc, ref_img, ref_st = orc.render(push, w, h, n_frames=n_frames, max_depth=max_depth, use_bvh=False)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.max_depth = max_depth
+    for k, v in kw.items():
+        setattr(rr, k, v)
+    for integrator in INTEGRATORS:
+        rr.integrator = integrator
+        R.reset_render(rr)
+        ctx.reset_stats()
+        rr.render(cam, frame=1, samples_per_frame=spf, n_frames=n_frames)
+        assert np.array_equal(_bits(rr.read_accum()), _bits(ref_acc)), integrator
+        assert np.array_equal(rr.read_rgba8(), ref_img), integrator
+        st = ctx.stats()
+        assert (st.rays, st.paths) == (ref_st.rays, ref_st.paths), integrator
+    rr.close()
+    dev.close()
+
+
+def test_scene_without_triangles(ctx, oracle):
+    """No geometry at all: every path ends at the sky after one ray."""
+    sky = scenes.procedural_sky(32, 16)
+    empty = R.Mesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
+    for sc in (R.Scene([], [], sky), R.Scene([empty], [R.Instance(R.IDENTITY, 0, 0)], None)):
+        _render_all(ctx, oracle, sc, 24, 10, n_frames=3, max_depth=4)
+        dev = R.DeviceScene(ctx, sc)
+        assert dev.info.n_triangles == 0
+        hits, _ = dev.trace(scenes.random_rays(100), count=True)
+        assert np.all(hits["flat"] == 0xFFFFFFFF)
+        dev.close()
+
+
+def test_degenerate_and_single_triangles(ctx, oracle):
+    """One triangle; zero-area and collinear triangles among good ones (they can
+    never be hit: det == 0) must not disturb the build or the traversal."""
+    p = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0],      # a real triangle
+                  [0.5, 0.5, -0.5], [0.5, 0.5, -0.5], [0.5, 0.5, -0.5],  # a point
+                  [-1, 0, -1], [0, 0, -1], [1, 0, -1]], np.float32)      # collinear
+    n = np.tile(np.array([0, 0, 1], np.float32), (9, 1))
+    one = R.Mesh(p[:3], n[:3], np.array([[0, 1, 2]], np.uint32))
+    mixed = R.Mesh(p, n, np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8]], np.uint32))
+    for mesh in (one, mixed):
+        sc = R.Scene([mesh], [R.Instance(R.IDENTITY, 0, 0), R.Instance(np.array(
+            [[0.5, 0, 0, 0], [0, 0.5, 0, 0.2], [0, 0, 0.5, 1.0]], np.float32), 0, 1)], None)
+        _render_all(ctx, oracle, sc, 33, 17, n_frames=4, max_depth=5)
+
+
+@pytest.mark.parametrize("max_depth", [1, 2])
+def test_shallow_depths(ctx, oracle, max_depth):
+    _render_all(ctx, oracle, scenes.cornell_box(tall_kind=1, short_kind=3), 40, 24, n_frames=3, max_depth=max_depth)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 2), (17, 1), (1, 19)])
+def test_tiny_films(ctx, oracle, w, h):
+    _render_all(ctx, oracle, scenes.cornell_box(), w, h, n_frames=20, max_depth=4)
+
+
+@pytest.mark.parametrize("spf", [1, 3])
+def test_workspace_bound_splits_a_call_into_batches(ctx, oracle, spf):
+    """max_paths_in_flight below one call's paths: several batches, the last one
+    partial, same film."""
+    w, h, n_frames = 20, 12, 37
+    _render_all(ctx, oracle, scenes.cornell_box(tall_kind=1), w, h, n_frames=n_frames, max_depth=5, spf=spf,
+                max_paths_in_flight=w * h * spf * 16 + 7)   # 16 dispatches per batch -> 16 + 16 + 5
+    _render_all(ctx, oracle, scenes.cornell_box(tall_kind=1), w, h, n_frames=5, max_depth=5, spf=spf,
+                max_paths_in_flight=1)                      # one dispatch at a time
+
+
+def test_continued_film_and_external_sample_count(ctx, oracle):
+    """draw_frame's bookkeeping (src/renderer.cpp:2018-2110): a film rendered in
+    pieces equals one rendered in a single call; ptc_film_set_sample_count moves
+    the running-mean weight as the host counter would."""
+    sc = scenes.cornell_box()
+    dev = R.DeviceScene(ctx, sc)
+    orc = oracle.Scene(*sc.oracle_args())
+    w, h = 28, 20
+    cam = R.default_camera(w, h)
+    ref_acc, ref_img, _ = orc.render(oracle.make_push(cam.as_dict(), frame=0), w, h, n_frames=7, max_depth=4,
+                                     use_bvh=False)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.max_depth = 4
+    for first, n in ((0, 1), (1, 3), (4, 2), (6, 1)):
+        rr.render(cam, frame=first, n_frames=n)
+    assert rr.sample_count == 7
+    assert np.array_equal(_bits(rr.read_accum()), _bits(ref_acc))
+    assert np.array_equal(rr.read_rgba8(), ref_img)
+    # the same last dispatch again, from the state before it
+    acc6, _, _ = orc.render(oracle.make_push(cam.as_dict(), frame=0), w, h, n_frames=6, max_depth=4, use_bvh=False)
+    rr2 = R.RenderResources(ctx, w, h, dev)
+    rr2.max_depth = 4
+    rr2.render(cam, frame=0, n_frames=6)
+    assert np.array_equal(_bits(rr2.read_accum()), _bits(acc6))
+    R._check(R.lib().ptc_film_set_sample_count(rr2.film, 6))
+    rr2.render(cam, frame=6, n_frames=1)
+    assert np.array_equal(_bits(rr2.read_accum()), _bits(ref_acc))
+    rr.close()
+    rr2.close()
+    dev.close()
+
+
+def test_caller_owned_film_buffers_and_device_rays(ctx, oracle):
+    """The film can live in caller-owned device memory (what an interop display
+    or a collective needs), and rays / hits can stay on the device."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.cornell_box(short_kind=1)
+    dev = R.DeviceScene(ctx, sc)
+    orc = oracle.Scene(*sc.oracle_args())
+    w, h = 32, 16
+    cam = R.default_camera(w, h)
+    accum = torch.full((h, w, 4), 7.0, dtype=torch.float32, device="cuda:0")
+    rgba8 = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    rr = R.RenderResources(ctx, w, h, dev, accum_dev=accum.data_ptr(), rgba8_dev=rgba8.data_ptr())
+    rr.max_depth = 4
+    rr.render(cam, frame=0, n_frames=2)
+    ctx.synchronize()
+    ref_acc, ref_img, _ = orc.render(oracle.make_push(cam.as_dict(), frame=0), w, h, n_frames=2, max_depth=4,
+                                     use_bvh=False)
+    assert np.array_equal(_bits(accum.cpu().numpy()), _bits(ref_acc))
+    assert np.array_equal(rgba8.cpu().numpy().view(np.uint8).reshape(h, w, 4), ref_img)
+    rays = scenes.random_rays(5000, seed=9)
+    d_rays = torch.from_numpy(rays).to("cuda:0")
+    d_hits = torch.zeros((rays.shape[0], 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    R._check(R.lib().ptc_trace_rays_device(ctx.handle, dev.handle, d_rays.data_ptr(), rays.shape[0], 0.0,
+                                           d_hits.data_ptr()))
+    ctx.synchronize()
+    got = d_hits.cpu().numpy().view(R.HIT_DTYPE).reshape(-1)
+    ref, _ = orc.intersect(rays, use_bvh=False)
+    assert np.array_equal(got["flat"], ref["id"])
+    hit = ref["id"] != oracle.NO_HIT
+    assert np.array_equal(_bits(got["t"][hit]), _bits(ref["t"][hit]))
+    rr.close()
+    dev.close()
+
+
+def test_argument_errors(ctx):
+    L = R.lib()
+    sc = scenes.cornell_box()
+    dev = R.DeviceScene(ctx, sc)
+    rr = R.RenderResources(ctx, 8, 8, dev)
+    cam = R.default_camera(8, 8)
+    p = R.RenderParams()
+    p.n_frames = 1
+    p.samples_per_frame = 1
+    assert L.ptc_render(ctx.handle, dev.handle, rr.film, None, C.byref(p)) == -1
+    assert L.ptc_render(ctx.handle, None, rr.film, C.byref(cam), C.byref(p)) == -1
+    assert b"NULL" in L.ptc_last_error()
+    p.integrator = 9
+    assert L.ptc_render(ctx.handle, dev.handle, rr.film, C.byref(cam), C.byref(p)) == -1
+    other = R.create_context(0)
+    p.integrator = 0
+    assert L.ptc_render(other.handle, dev.handle, rr.film, C.byref(cam), C.byref(p)) == -1
+    assert b"another context" in L.ptc_last_error()
+    other.close()
+    h = C.c_void_p()
+    assert L.ptc_film_create(ctx.handle, 0, 4, None, None, C.byref(h)) == -1
+    with pytest.raises(R.PtcError):
+        R.DeviceScene(ctx, R.Scene([sc.meshes[0]], [R.Instance(R.IDENTITY, 3, 0)], None))  # mesh index out of range
+    with pytest.raises(R.PtcError):
+        R.DeviceScene(ctx, R.Scene([sc.meshes[0]], [R.Instance(R.IDENTITY, 0, 7)], None))  # unknown material kind
+    bad = R.Mesh(sc.meshes[0].positions, sc.meshes[0].normals, sc.meshes[0].indices + 10 ** 6)
+    with pytest.raises(R.PtcError):
+        R.DeviceScene(ctx, R.Scene([bad], [R.Instance(R.IDENTITY, 0, 0)], None))           # vertex index out of range
+    rr.close()
+    dev.close()
