@@ -320,7 +320,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // rarer phases (pulling new paths, shading, triangle tests) run when
     // enough lanes of the wave want them, or when a lane has nothing else left.
     constexpr uint32_t kIdle = 0u, kTrav = 1u, kShade = 2u;
-    constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 16u; // lanes that must want a phase before it runs
+    constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 16u, kTriMoreMin = 16u; // lanes that must want a phase before it runs
     uint32_t mode = kIdle;
     constexpr uint32_t kChunk = 128u; // work items a wave reserves per atomic
     uint32_t chunk_next = 0u, chunk_end = 0u; // this wave's reserved items not handed out yet
@@ -487,6 +487,19 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
             tg.y &= tg.y - 1u;
             tri_test(S, R, tg.x + i, best);
+        }
+        // Lanes with triangles left but no node to visit would spend the next
+        // iteration on one triangle alone. When many lanes of the wave are in
+        // that state (scenes with few, large leaves) they test one more right away.
+        const bool more = mode == kTrav && tg.y != 0u && !(ng.y & kNodeBits);
+        if ((uint32_t)__builtin_popcountll(__ballot(more)) >= kTriMoreMin)
+        {
+            if (more)
+            {
+                const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
+                tg.y &= tg.y - 1u;
+                tri_test(S, R, tg.x + i, best);
+            }
         }
     }
     unsigned long long wr = rays;
