@@ -488,10 +488,9 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             tg.y &= tg.y - 1u;
             tri_test(S, R, tg.x + i, best);
         }
-        // Lanes with triangles left but no node to visit would spend the next
-        // iteration on one triangle alone. When many lanes of the wave are in
-        // that state (scenes with few, large leaves) they test one more right away.
-        const bool more = mode == kTrav && tg.y != 0u && !(ng.y & kNodeBits);
+        // When many lanes of the wave still have triangles pending (scenes with
+        // few, large leaves are bound by this), they test one more right away.
+        const bool more = mode == kTrav && tg.y != 0u;
         if ((uint32_t)__builtin_popcountll(__ballot(more)) >= kTriMoreMin)
         {
             if (more)
