@@ -173,8 +173,13 @@ def main():
     for k in range(args.steps):
         step(k)
     ctx.synchronize()
+    reduce_ms = None
     if world > 1:
+        # the one collective of the run: per-rank sums -> rank 0 (timed on its own as well)
+        t_red = time.perf_counter()
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        reduce_ms = (time.perf_counter() - t_red) * 1e3
     sync_all()
     elapsed = time.perf_counter() - t0
 
@@ -225,6 +230,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ms_per_spp": round(elapsed / total_spp * 1e3, 4),
+            "reduce_ms": None if reduce_ms is None else round(reduce_ms, 3),
             "rays_per_path": round(total_rays / max(total_paths, 1.0), 3),
             "config": {"workload": f"{scene_desc}; {W}x{H}, {spp} spp per GPU per step, "
                                    f"max depth {args.max_depth}, {args.integrator}, spp sharded "
