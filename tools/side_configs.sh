@@ -8,4 +8,5 @@ timeout -k 10 400 $B --scene torus10m --max-depth 8 --spp-per-step 32 &&
 timeout -k 10 300 $B --width 3840 --height 2160 --spp-per-step 16 &&
 timeout -k 10 300 $B --width 3840 --height 2160 --spp-per-step 16 --integrator megakernel &&
 timeout -k 10 200 $B --scene cornell --width 1024 --height 1024 --max-depth 8 --spp-per-step 64 &&
-timeout -k 10 200 $B --scene cornell --width 512 --height 512 --max-depth 8 --spp-per-step 16
+timeout -k 10 200 $B --scene cornell --width 512 --height 512 --max-depth 8 --spp-per-step 16 &&
+timeout -k 10 300 $B --scene ref4
