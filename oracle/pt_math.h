@@ -135,6 +135,16 @@ static inline pt_vec3 pt_xform_point(const float *m, pt_vec3 p)
     return r;
 }
 
+/* linear part of the 3x4 matrix m times d (a direction: no translation) */
+static inline pt_vec3 pt_xform_vector(const float *m, pt_vec3 d)
+{
+    pt_vec3 r;
+    r.x = fmaf(m[2], d.z, fmaf(m[1], d.y, m[0] * d.x));
+    r.y = fmaf(m[6], d.z, fmaf(m[5], d.y, m[4] * d.x));
+    r.z = fmaf(m[10], d.z, fmaf(m[9], d.y, m[8] * d.x));
+    return r;
+}
+
 /* row vector n times the 3x3 linear part of the 3x4 matrix m:
  * r[c] = n.x*m[0][c] + n.y*m[1][c] + n.z*m[2][c]
  * (GLSL "vec3 * mat4x3 .xyz", closest_hit_common.glsl:82) */

@@ -454,6 +454,9 @@ struct pt_scene
     uint32_t n_nodes;
     uint32_t *prim_order; /* leaf slots -> flat triangle index */
     double sah_cost;
+    /* two-level mode: closest hits are defined in object space, instance by
+     * instance (see intersect_two_level) */
+    int two_level;
 };
 
 /* Inverse of a 3x4 affine matrix: cofactor formula evaluated in double,
@@ -723,6 +726,52 @@ static pt_hit intersect_brute(const pt_scene *S, pt_vec3 o, pt_vec3 d,
         st->tris_tested += S->n_tris;
     }
     return best;
+}
+
+/* Two-level closest hit, the shape of the reference's TLAS of instances over
+ * one BLAS per mesh (src/renderer.cpp:1044-1281): for every instance the ray
+ * is taken to object space with the instance's world-to-object matrix
+ * (origin as a point, direction as a vector, not re-normalised, so t keeps its
+ * meaning), and Moller-Trumbore runs on the mesh's own vertices (v0, e1 = v1 -
+ * v0, e2 = v2 - v0 in object space). The hit is the lexicographic minimum over
+ * (t, flattened triangle index) as in the flattened definition; the two
+ * definitions agree up to the rounding of the transforms. Brute force only. */
+static pt_hit intersect_two_level(const pt_scene *S, pt_vec3 o, pt_vec3 d,
+                                  float tmax, pt_stats *st)
+{
+    pt_hit best = {tmax, 0.0f, 0.0f, PT_NO_HIT};
+    for (uint32_t i = 0; i < S->n_insts; ++i)
+    {
+        const inst_t *I = &S->insts[i];
+        const mesh_t *M = &S->meshes[I->mesh];
+        const pt_vec3 ro = pt_xform_point(I->w2o, o);
+        const pt_vec3 rd = pt_xform_vector(I->w2o, d);
+        for (uint32_t f = 0; f < M->n_triangles; ++f)
+        {
+            const pt_vec3 a = ld3(M->positions + 3 * M->indices[3 * f + 0]);
+            const pt_vec3 b = ld3(M->positions + 3 * M->indices[3 * f + 1]);
+            const pt_vec3 c = ld3(M->positions + 3 * M->indices[3 * f + 2]);
+            wtri_t T;
+            T.v0 = a;
+            T.e1 = pt_sub(b, a);
+            T.e2 = pt_sub(c, a);
+            float t, u, v;
+            if (mt_test(ro, rd, &T, tmax, &t, &u, &v))
+            {
+                consider(&best, t, u, v, I->first_flat + f);
+            }
+        }
+        if (st)
+        {
+            st->tris_tested += M->n_triangles;
+        }
+    }
+    return best;
+}
+
+void pt_scene_set_two_level(pt_scene *S, int enabled)
+{
+    S->two_level = enabled != 0;
 }
 
 /* --- oracle BVH: binned SAH, binary, float boxes ---------------------------*/
@@ -1050,6 +1099,10 @@ static pt_hit intersect_bvh(const pt_scene *S, pt_vec3 o, pt_vec3 d, float tmax,
 static inline pt_hit intersect_any(const pt_scene *S, pt_vec3 o, pt_vec3 d,
                                    float tmax, int use_bvh, pt_stats *st)
 {
+    if (S->two_level)
+    {
+        return intersect_two_level(S, o, d, tmax, st);
+    }
     return use_bvh ? intersect_bvh(S, o, d, tmax, st)
                    : intersect_brute(S, o, d, tmax, st);
 }

@@ -126,6 +126,9 @@ pt_scene *pt_scene_create(const pt_mesh_desc *meshes, uint32_t n_meshes,
                           uint32_t n_instances, const float *env_rgba,
                           uint32_t env_width, uint32_t env_height);
 void pt_scene_destroy(pt_scene *scene);
+/* Closest hits instance by instance in object space (two-level definition)
+ * instead of on the flattened world-space triangles; brute force only. */
+void pt_scene_set_two_level(pt_scene *scene, int enabled);
 uint32_t pt_scene_triangle_count(const pt_scene *scene);
 /* flattened index -> (instance, primitive) */
 void pt_scene_triangle_ids(const pt_scene *scene, uint32_t flat,

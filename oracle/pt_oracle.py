@@ -108,6 +108,8 @@ def lib():
         L.pt_scene_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                       C.c_void_p, C.c_uint32, C.c_uint32]
         L.pt_scene_destroy.argtypes = [C.c_void_p]
+        L.pt_scene_set_two_level.argtypes = [C.c_void_p, C.c_int]
+        L.pt_scene_set_two_level.restype = None
         L.pt_scene_triangle_count.restype = C.c_uint32
         L.pt_scene_triangle_count.argtypes = [C.c_void_p]
         L.pt_scene_triangle_ids.argtypes = [C.c_void_p, C.c_uint32,
@@ -260,8 +262,9 @@ class Scene:
     """meshes: list of (positions f32[V,3], normals f32[V,3], indices u32[F,3]);
     instances: list of (transform 3x4, mesh index, kind); env: f32[H,W,4] or None."""
 
-    def __init__(self, meshes, instances, env=None):
+    def __init__(self, meshes, instances, env=None, two_level=False):
         L = lib()
+        self._two_level = two_level
         self._keep = []
         md = (MeshDesc * max(1, len(meshes)))()
         for i, (p, n, idx) in enumerate(meshes):
@@ -289,6 +292,8 @@ class Scene:
             eptr = env.ctypes.data
         self.handle = L.pt_scene_create(md, len(meshes), idesc, len(instances), eptr, ew, eh)
         self.n_triangles = L.pt_scene_triangle_count(self.handle)
+        if two_level:
+            L.pt_scene_set_two_level(self.handle, 1)
 
     def __del__(self):
         if getattr(self, "handle", None):
