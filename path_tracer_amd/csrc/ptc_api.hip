@@ -367,6 +367,11 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
             return PTC_E_LIMIT;
         }
     }
+    if (opts && opts->two_level && n_instances > PTC_MAX_TWO_LEVEL_INSTANCES)
+    {
+        set_error("ptc_scene_create: too many instances for a two-level scene");
+        return PTC_E_LIMIT;
+    }
     if (envmap && envmap->rgba && (envmap->width == 0 || envmap->height == 0))
     {
         set_error("ptc_scene_create: empty environment map");
@@ -442,12 +447,38 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
     S->info.n_triangles = (uint32_t)total;
     S->info.n_instances = n_instances;
 
-    rc = build_bvh(ctx, S, inst, (uint32_t)total, opts ? opts->search_radius : 0u);
+    if (opts && opts->two_level)
+    {
+        // object-space box of every mesh, from the host arrays
+        std::vector<float> mesh_box(6 * std::max<size_t>(n_meshes, 1), 0.0f);
+        for (uint32_t m = 0; m < n_meshes; ++m)
+        {
+            float *b = &mesh_box[6 * (size_t)m];
+            b[0] = b[1] = b[2] = INFINITY;
+            b[3] = b[4] = b[5] = -INFINITY;
+            for (size_t v = 0; v < 3 * (size_t)meshes[m].n_vertices; ++v)
+            {
+                b[v % 3] = std::min(b[v % 3], meshes[m].positions[v]);
+                b[3 + v % 3] = std::max(b[3 + v % 3], meshes[m].positions[v]);
+            }
+        }
+        std::vector<uint32_t> mesh_of(n_instances);
+        for (uint32_t i = 0; i < n_instances; ++i)
+        {
+            mesh_of[i] = instances[i].mesh;
+        }
+        rc = build_two_level(ctx, S, inst, vtx_off, tri_off, mesh_box, mesh_of, opts->search_radius);
+    }
+    else
+    {
+        rc = build_bvh(ctx, S, inst, (uint32_t)total, opts ? opts->search_radius : 0u);
+    }
     if (rc != PTC_OK)
     {
         return fail(rc);
     }
-    S->info.device_bytes = (uint64_t)S->info.n_nodes * 80 + (uint64_t)total * 48 + nv * 24 + nt * 12 +
+    S->info.device_bytes = (uint64_t)S->info.n_nodes * 80 + (uint64_t)(S->d_inst_box ? nt : total) * 48 + nv * 24 +
+                           nt * 12 + (S->d_inst_box ? n_instances * 32 : 0) +
                            n_instances * sizeof(DInstance) +
                            (S->d_env ? (uint64_t)S->d.env_w * S->d.env_h * 16 : 0);
     *out = S;
@@ -468,6 +499,7 @@ void ptc_scene_destroy(ptc_scene *scene)
     (void)hipFree(scene->d_normals);
     (void)hipFree(scene->d_indices);
     (void)hipFree(scene->d_instances);
+    (void)hipFree(scene->d_inst_box);
     (void)hipFree(scene->d_env);
     delete scene;
 }

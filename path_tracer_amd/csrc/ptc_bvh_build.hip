@@ -1095,4 +1095,195 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
     return PTC_OK;
 }
 
+namespace
+{
+// child and triangle indices of a mesh's tree, moved to where the tree sits in
+// the concatenated arrays
+__global__ void __launch_bounds__(kBlock)
+k_rebase_nodes(uint4 *__restrict__ nodes, uint32_t n_nodes, uint32_t node_off, uint32_t tri_off)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_nodes)
+    {
+        uint4 w1 = nodes[5u * (size_t)i + 1u];
+        w1.x += node_off;
+        w1.y += tri_off;
+        nodes[5u * (size_t)i + 1u] = w1;
+    }
+}
+} // namespace
+
+int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &instances,
+                    const std::vector<uint32_t> &vtx_off, const std::vector<uint32_t> &tri_off,
+                    const std::vector<float> &mesh_box, const std::vector<uint32_t> &mesh_of,
+                    uint32_t search_radius)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t n_meshes = (uint32_t)vtx_off.size() - 1u;
+    // one identity pseudo-instance per mesh drives the ordinary builder
+    std::vector<DInstance> pseudo(std::max<uint32_t>(n_meshes, 1u));
+    for (uint32_t m = 0; m < n_meshes; ++m)
+    {
+        DInstance &P = pseudo[m];
+        std::memset(&P, 0, sizeof P);
+        P.o2w[0] = P.o2w[5] = P.o2w[10] = 1.0f;
+        P.w2o[0] = P.w2o[5] = P.w2o[10] = 1.0f;
+        P.vtx_offset = vtx_off[m];
+        P.tri_offset = tri_off[m];
+        P.n_tris = tri_off[m + 1] - tri_off[m];
+    }
+    DInstance *d_pseudo = nullptr;
+    PTC_HIP_CHECK(hipMalloc(&d_pseudo, pseudo.size() * sizeof(DInstance)));
+    struct Built
+    {
+        void *nodes = nullptr, *tris = nullptr;
+        uint32_t n_nodes = 0, n_tris = 0, depth = 0;
+    };
+    std::vector<Built> built(n_meshes);
+    auto cleanup = [&]() {
+        (void)hipFree(d_pseudo);
+        for (Built &b : built)
+        {
+            (void)hipFree(b.nodes);
+            (void)hipFree(b.tris);
+        }
+    };
+    hipError_t e = hipMemcpyAsync(d_pseudo, pseudo.data(), pseudo.size() * sizeof(DInstance), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess)
+    {
+        cleanup();
+        set_error(std::string("two-level build: ") + hipGetErrorString(e));
+        return PTC_E_DEVICE;
+    }
+    float build_ms = 0.0f;
+    double sah_weighted = 0.0;
+    uint32_t total_nodes = 0, total_tris = 0, depth = 0;
+    for (uint32_t m = 0; m < n_meshes; ++m)
+    {
+        const uint32_t nt = pseudo[m].n_tris;
+        if (nt == 0)
+        {
+            continue;
+        }
+        ptc_scene sub;
+        sub.ctx = ctx;
+        sub.d_positions = scene->d_positions;
+        sub.d_indices = scene->d_indices;
+        sub.d_instances = d_pseudo + m;
+        const std::vector<DInstance> one(1, pseudo[m]);
+        const int rc = build_bvh(ctx, &sub, one, nt, search_radius);
+        built[m].nodes = sub.d_nodes;
+        built[m].tris = sub.d_tris;
+        if (rc != PTC_OK)
+        {
+            cleanup();
+            return rc;
+        }
+        built[m].n_nodes = sub.info.n_nodes;
+        built[m].n_tris = nt;
+        built[m].depth = sub.info.bvh_depth;
+        build_ms += sub.info.build_ms;
+        sah_weighted += (double)sub.info.sah_cost * nt;
+        depth = std::max(depth, sub.info.bvh_depth);
+        total_nodes += sub.info.n_nodes;
+        total_tris += nt;
+    }
+    e = hipMalloc(&scene->d_nodes, std::max<size_t>(total_nodes, 1) * 80);
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(&scene->d_tris, std::max<size_t>(total_tris, 1) * 48);
+    }
+    std::vector<uint32_t> root_of(n_meshes, kNoBlas);
+    uint32_t node_off = 0, tri_at = 0;
+    for (uint32_t m = 0; m < n_meshes && e == hipSuccess; ++m)
+    {
+        const Built &b = built[m];
+        if (b.n_tris == 0)
+        {
+            continue;
+        }
+        uint4 *dst = static_cast<uint4 *>(scene->d_nodes) + 5u * (size_t)node_off;
+        e = hipMemcpyAsync(dst, b.nodes, (size_t)b.n_nodes * 80, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess)
+        {
+            e = hipMemcpyAsync(static_cast<char *>(scene->d_tris) + (size_t)tri_at * 48, b.tris, (size_t)b.n_tris * 48,
+                               hipMemcpyDeviceToDevice, st);
+        }
+        if (e == hipSuccess)
+        {
+            k_rebase_nodes<<<blocks_for(b.n_nodes), kBlock, 0, st>>>(dst, b.n_nodes, node_off, tri_at);
+            e = hipGetLastError();
+        }
+        root_of[m] = node_off;
+        node_off += b.n_nodes;
+        tri_at += b.n_tris;
+    }
+    // instance records: root of the mesh's tree; world box = the eight corners of
+    // the mesh box through o2w, padded (the box only decides whether the
+    // instance is entered, so generous padding costs time, never a hit)
+    const size_t n_inst = instances.size();
+    std::vector<float4> boxes(2 * std::max<size_t>(n_inst, 1));
+    for (size_t i = 0; i < n_inst; ++i)
+    {
+        DInstance &I = instances[i];
+        const uint32_t m = mesh_of[i];
+        I.blas_root = root_of[m];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (I.blas_root != kNoBlas)
+        {
+            const float *mb = &mesh_box[6 * (size_t)m];
+            float big = 0.0f;
+            for (int c = 0; c < 8; ++c)
+            {
+                const float p[3] = {mb[(c & 1) ? 3 : 0], mb[(c & 2) ? 4 : 1], mb[(c & 4) ? 5 : 2]};
+                for (int r = 0; r < 3; ++r)
+                {
+                    const float w = I.o2w[4 * r] * p[0] + I.o2w[4 * r + 1] * p[1] + I.o2w[4 * r + 2] * p[2] + I.o2w[4 * r + 3];
+                    lo[r] = std::min(lo[r], w);
+                    hi[r] = std::max(hi[r], w);
+                    big = std::max(big, std::fabs(w));
+                }
+            }
+            const float pad = big * (1.0f / 4096.0f) + 1e-30f;
+            for (int r = 0; r < 3; ++r)
+            {
+                lo[r] -= pad;
+                hi[r] += pad;
+            }
+        }
+        boxes[2 * i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        boxes[2 * i + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(&scene->d_inst_box, boxes.size() * sizeof(float4));
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMemcpyAsync(scene->d_inst_box, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice, st);
+    }
+    if (e == hipSuccess && n_inst)
+    {
+        e = hipMemcpyAsync(scene->d_instances, instances.data(), n_inst * sizeof(DInstance), hipMemcpyHostToDevice, st);
+    }
+    if (e == hipSuccess)
+    {
+        e = hipStreamSynchronize(st);
+    }
+    cleanup();
+    if (e != hipSuccess)
+    {
+        set_error(std::string("two-level build: ") + hipGetErrorString(e));
+        return PTC_E_DEVICE;
+    }
+    scene->d.nodes = static_cast<const uint4 *>(scene->d_nodes);
+    scene->d.tris = static_cast<const float4 *>(scene->d_tris);
+    scene->d.inst_box = scene->d_inst_box;
+    scene->info.n_nodes = total_nodes;
+    scene->info.bvh_depth = depth;
+    scene->info.build_ms = build_ms;
+    scene->info.sah_cost = total_tris ? (float)(sah_weighted / total_tris) : 1.0f;
+    return PTC_OK;
+}
+
 } // namespace ptc

@@ -20,8 +20,10 @@ struct DInstance // 128 bytes
     uint32_t tri_offset; // first triangle of the mesh in the shared index array
     uint32_t first_flat; // flattened index of this instance's primitive 0
     uint32_t n_tris;
-    uint32_t pad[3];
+    uint32_t blas_root;  // two-level scenes: root node of the mesh's own tree (kNoBlas: no triangles)
+    uint32_t pad[2];
 };
+constexpr uint32_t kNoBlas = 0xffffffffu;
 
 struct DScene
 {
@@ -31,6 +33,10 @@ struct DScene
     const float *__restrict__ normals;
     const uint32_t *__restrict__ indices; // 3 per triangle, mesh-local vertex ids
     const DInstance *__restrict__ instances;
+    // two-level scenes only (nullptr otherwise): world-space box of every
+    // instance, (lo, hi) pairs; nodes / tris then hold one tree per mesh in
+    // object space and rays enter an instance through its w2o matrix
+    const float4 *__restrict__ inst_box;
     const float4 *__restrict__ env; // RGBA32F equirect map or nullptr
     uint32_t env_w, env_h;
     uint32_t n_instances;
@@ -807,7 +813,7 @@ PTC_DEV uint2 stack_pop(uint2 *lds, uint32_t stride, const uint2 *spill, int &sp
 // reproducible.)
 template <bool kCount, int kLds = kLdsStack>
 PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_stack,
-                          uint32_t stride, TraceCounters *ctr)
+                          uint32_t stride, TraceCounters *ctr, uint32_t root = 0u)
 {
     Hit best = no_hit(tmax);
     if (S.n_tris == 0u)
@@ -817,7 +823,7 @@ PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *ld
     const RayCtx R = make_ray_ctx(o, d, tmax);
     uint2 spill[kStackTotal - kLds];
     int sp = 0;
-    uint2 ng = make_uint2(0u, 0x80000000u);
+    uint2 ng = make_uint2(root, 0x80000000u);
     for (;;)
     {
         const uint32_t node_idx = next_child(ng, R.octinv);
@@ -862,7 +868,7 @@ PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *ld
 // the visit order.
 template <int kLds = kLdsStack>
 PTC_DEV Hit trace_closest_interleaved(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_stack,
-                                      uint32_t stride)
+                                      uint32_t stride, uint32_t root = 0u)
 {
     Hit best = no_hit(tmax);
     if (S.n_tris == 0u)
@@ -872,7 +878,7 @@ PTC_DEV Hit trace_closest_interleaved(const DScene &S, vec3 o, vec3 d, float tma
     const RayCtx R = make_ray_ctx(o, d, tmax);
     uint2 spill[kStackTotal - kLds];
     int sp = 0;
-    uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
+    uint2 ng = make_uint2(root, 0x80000000u), tg = make_uint2(0u, 0u);
     for (;;)
     {
         if (!(ng.y & kNodeBits) && tg.y == 0u)
@@ -914,6 +920,68 @@ PTC_DEV Hit trace_closest_interleaved(const DScene &S, vec3 o, vec3 d, float tma
     return best;
 }
 
+// Two-level scenes, the structure of the reference's TLAS over one BLAS per
+// mesh (src/renderer.cpp:1044-1281): the instances are walked in order; a ray
+// that meets an instance's world box is taken to object space with the
+// instance's w2o matrix (origin as a point, direction as a vector and not
+// re-normalised, so t keeps its meaning) and traverses the mesh's own tree
+// with the current best t as its limit. Instances later in the list have
+// larger flattened indices, so the strict t < limit of the triangle test is
+// exactly the (t, flat) order of the hit definition. The list is linear: the
+// reference's instance counts are a handful.
+template <bool kCount, int kLds = kLdsStack>
+PTC_DEV Hit trace_two_level(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_stack, uint32_t stride,
+                            TraceCounters *ctr)
+{
+    Hit best = no_hit(tmax);
+    const float idx = 1.0f / clamp_dir(d.x), idy = 1.0f / clamp_dir(d.y), idz = 1.0f / clamp_dir(d.z);
+    for (uint32_t i = 0; i < S.n_instances; ++i)
+    {
+        // conservative slab test against the (padded) world box
+        const float4 lo = S.inst_box[2u * i], hi = S.inst_box[2u * i + 1u];
+        const float ax = (lo.x - o.x) * idx, bx = (hi.x - o.x) * idx;
+        const float ay = (lo.y - o.y) * idy, by = (hi.y - o.y) * idy;
+        const float az = (lo.z - o.z) * idz, bz = (hi.z - o.z) * idz;
+        const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
+        const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
+        const float slack = (__builtin_fabsf(tn) + __builtin_fabsf(tf)) * kSlabSlack;
+        if (!(tn - slack <= tf + slack) || !(tf + slack >= 0.0f) || !(tn - slack <= best.t * kTLimitPad))
+        {
+            continue;
+        }
+        const DInstance *__restrict__ I = &S.instances[i];
+        const uint32_t root = I->blas_root;
+        if (root == kNoBlas)
+        {
+            continue;
+        }
+        const vec3 ro = xform_point(I->w2o, o);
+        const vec3 rd = xform_vector(I->w2o, d);
+        const Hit h = kCount ? trace_closest<true, kLds>(S, ro, rd, best.t, lds_stack, stride, ctr, root)
+                             : trace_closest_interleaved<kLds>(S, ro, rd, best.t, lds_stack, stride, root);
+        if (h.flat != kNoHit)
+        {
+            best = h;
+            best.instance = i;
+            best.flat = I->first_flat + h.primitive;
+        }
+    }
+    return best;
+}
+
+// The closest-hit query of whichever kind the scene was built for.
+template <bool kCount, int kLds = kLdsStack>
+PTC_DEV Hit trace_scene(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_stack, uint32_t stride,
+                        TraceCounters *ctr)
+{
+    if (S.inst_box != nullptr)
+    {
+        return trace_two_level<kCount, kLds>(S, o, d, tmax, lds_stack, stride, ctr);
+    }
+    return kCount ? trace_closest<true, kLds>(S, o, d, tmax, lds_stack, stride, ctr)
+                  : trace_closest_interleaved<kLds>(S, o, d, tmax, lds_stack, stride);
+}
+
 // ---- path loop: shader.rgen:60-100 -------------------------------------------
 
 template <bool kCount>
@@ -929,8 +997,7 @@ PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, vec3 origin, vec3 dir, u
     for (uint32_t bounces = 0; bounces < f.max_depth; ++bounces)
     {
         // counting runs use the reproducible visit order, plain runs the faster one
-        const Hit h = kCount ? trace_closest<true>(S, ps.origin, ps.dir, f.tmax, lds_stack, stride, ctr)
-                             : trace_closest_interleaved(S, ps.origin, ps.dir, f.tmax, lds_stack, stride);
+        const Hit h = trace_scene<kCount>(S, ps.origin, ps.dir, f.tmax, lds_stack, stride, ctr);
         ++rays;
         if (!path_bounce(S, h, ps))
         {

@@ -85,6 +85,16 @@ PTC_DEV vec3 xform_point(const float *__restrict__ m, vec3 p)
     return r;
 }
 
+// linear part of the 3x4 matrix m times d (a direction: no translation)
+PTC_DEV vec3 xform_vector(const float *__restrict__ m, vec3 d)
+{
+    vec3 r;
+    r.x = __builtin_fmaf(m[2], d.z, __builtin_fmaf(m[1], d.y, m[0] * d.x));
+    r.y = __builtin_fmaf(m[6], d.z, __builtin_fmaf(m[5], d.y, m[4] * d.x));
+    r.z = __builtin_fmaf(m[10], d.z, __builtin_fmaf(m[9], d.y, m[8] * d.x));
+    return r;
+}
+
 // row vector n times the 3x3 linear part of the 3x4 matrix m
 // (GLSL "vec3 * mat4x3 .xyz", closest_hit_common.glsl:82)
 PTC_DEV vec3 xform_normal_rowvec(const float *__restrict__ m, vec3 n)

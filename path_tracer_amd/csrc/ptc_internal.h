@@ -71,6 +71,7 @@ struct ptc_scene
     float *d_normals = nullptr;
     uint32_t *d_indices = nullptr;
     ptc::DInstance *d_instances = nullptr;
+    float4 *d_inst_box = nullptr; // two-level scenes: (lo, hi) world box per instance
     float4 *d_env = nullptr;
     ptc_scene_info info{};
 };
@@ -127,6 +128,13 @@ struct PhaseTimer
 // d.nodes, d.tris and the BVH fields of scene->info.
 int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &instances,
               uint32_t n_flat_tris, uint32_t search_radius);
+// Two-level variant: one tree per mesh in object space (concatenated into
+// d_nodes / d_tris), instances[i].blas_root and the world boxes in d_inst_box.
+// mesh_box holds (lo.xyz, hi.xyz) of every mesh in object space.
+int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &instances,
+                    const std::vector<uint32_t> &vtx_off, const std::vector<uint32_t> &tri_off,
+                    const std::vector<float> &mesh_box, const std::vector<uint32_t> &mesh_of,
+                    uint32_t search_radius);
 
 // Render kernels (ptc_render.hip, ptc_wavefront.hip).
 int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &frame,

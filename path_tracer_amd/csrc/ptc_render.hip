@@ -104,7 +104,7 @@ k_primary_hits(DScene S, DFrame F, uint32_t *__restrict__ ids)
     uint32_t rng = seed_(i, F.global_frame_count);
     vec3 o, d;
     camera_ray(F, px, py, rng, o, d);
-    const Hit h = trace_closest<false>(S, o, d, F.tmax, s_stack + threadIdx.x, kBlock, nullptr);
+    const Hit h = trace_scene<false>(S, o, d, F.tmax, s_stack + threadIdx.x, kBlock, nullptr);
     ids[i] = h.flat;
 }
 
@@ -122,7 +122,11 @@ k_trace(DScene S, const float *__restrict__ rays, size_t n, float tmax, ptc_hit 
     {
         const vec3 o = v3(rays[6 * i + 0], rays[6 * i + 1], rays[6 * i + 2]);
         const vec3 d = v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-        const Hit h = trace_closest<kCount>(S, o, d, tmax, s_stack + threadIdx.x, kBlock, &ctr);
+        // without counters the plain visit order of trace_closest is kept here too:
+        // this entry point is the one whose hits and counts the checker reproduces
+        const Hit h = S.inst_box != nullptr
+                          ? trace_two_level<kCount>(S, o, d, tmax, s_stack + threadIdx.x, kBlock, &ctr)
+                          : trace_closest<kCount>(S, o, d, tmax, s_stack + threadIdx.x, kBlock, &ctr);
         ptc_hit out;
         out.t = h.t;
         out.u = h.u;

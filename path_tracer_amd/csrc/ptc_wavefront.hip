@@ -197,8 +197,8 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
         alive = F.max_depth > 0u;
         if (alive)
         {
-            const Hit h = trace_closest_interleaved<kPrimaryLds>(S, ps.origin, ps.dir, F.tmax,
-                                                                 s_stack + threadIdx.x, kBlock);
+            const Hit h = trace_scene<false, kPrimaryLds>(S, ps.origin, ps.dir, F.tmax, s_stack + threadIdx.x,
+                                                          kBlock, nullptr);
             alive = path_bounce(S, h, ps) && F.max_depth > 1u;
         }
         if (!alive)
@@ -243,8 +243,8 @@ k_wf_trace(DScene S, float tmax, WfState q, float4 *__restrict__ hit, uint2 *__r
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
     {
         const float4 a = q.a[i], b = q.b[i];
-        const Hit h = trace_closest_interleaved(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), tmax,
-                                                s_stack + threadIdx.x, kBlock);
+        const Hit h = trace_scene<false>(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), tmax, s_stack + threadIdx.x,
+                                         kBlock, nullptr);
         hit[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.flat));
         hit_ids[i] = make_uint2(h.instance, h.primitive);
     }
@@ -588,7 +588,11 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     hipStream_t st = ctx->stream;
     const uint32_t n_pixels = F0.width * F0.height;
     const uint32_t spf = F0.samples_per_frame;
-    const uint32_t wf_bounces = F0.wavefront_bounces;
+    // the persistent kernel walks one flattened tree: two-level scenes run every
+    // bounce as a traversal / shading launch pair instead
+    const bool two_level = scene->d.inst_box != nullptr;
+    const uint32_t wf_bounces = two_level ? F0.max_depth : F0.wavefront_bounces;
+    stream = stream && !two_level;
     // dispatches per batch: bounded so the workspace stays bounded (by default 2^27 paths, about 21 GB)
     const uint32_t max_batch = std::max<uint32_t>(
         1u, std::min<uint64_t>(F0.n_frames,

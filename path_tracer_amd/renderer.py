@@ -88,7 +88,7 @@ IMPORT_NO_NORMALIZE, IMPORT_NO_JOIN = 1, 2
 
 
 class BuildOptions(C.Structure):
-    _fields_ = [("search_radius", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+    _fields_ = [("search_radius", C.c_uint32), ("two_level", C.c_uint32), ("reserved", C.c_uint32 * 6)]
 
 
 class SceneInfo(C.Structure):
@@ -373,8 +373,9 @@ def create_context(device: int = 0) -> RenderContext:
 
 
 class DeviceScene:
-    def __init__(self, ctx: RenderContext, scene: Scene, search_radius: int = 0):
+    def __init__(self, ctx: RenderContext, scene: Scene, search_radius: int = 0, two_level: bool = False):
         self.ctx = ctx
+        self.two_level = two_level
         keep = []
         md = (MeshDesc * max(1, len(scene.meshes)))()
         for i, m in enumerate(scene.meshes):
@@ -399,6 +400,7 @@ class DeviceScene:
             env = EnvmapDesc(e.ctypes.data, e.shape[1], e.shape[0])
         opts = BuildOptions()
         opts.search_radius = search_radius
+        opts.two_level = int(two_level)
         h = C.c_void_p()
         _check(lib().ptc_scene_create(ctx.handle, md, len(scene.meshes), idesc,
                                       len(scene.instances), C.byref(env) if env else None,
@@ -448,10 +450,10 @@ class RenderResources:
     + render target + the three sample counters the UI edits."""
 
     def __init__(self, ctx: RenderContext, width: int, height: int, scene,
-                 accum_dev: int = 0, rgba8_dev: int = 0, search_radius: int = 0):
+                 accum_dev: int = 0, rgba8_dev: int = 0, search_radius: int = 0, two_level: bool = False):
         self.ctx = ctx
         self.width, self.height = width, height
-        self.scene = scene if isinstance(scene, DeviceScene) else DeviceScene(ctx, scene, search_radius)
+        self.scene = scene if isinstance(scene, DeviceScene) else DeviceScene(ctx, scene, search_radius, two_level)
         h = C.c_void_p()
         _check(lib().ptc_film_create(ctx.handle, width, height, C.c_void_p(accum_dev or None),
                                      C.c_void_p(rgba8_dev or None), C.byref(h)))

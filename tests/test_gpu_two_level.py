@@ -1,0 +1,96 @@
+"""Two-level scenes (one tree per mesh in object space + an instance list, the
+structure of the reference's TLAS over one BLAS, src/renderer.cpp:1044-1281)
+against the oracle's two-level closest-hit definition. Bar: bit-exact."""
+import numpy as np
+import pytest
+
+from path_tracer_amd import renderer as R
+from path_tracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _scenes():
+    knot = scenes.knot_mesh(nu=40, nv=10)
+    rot = np.array([[0.6, -0.8, 0, 0.3], [0.8, 0.6, 0, -0.2], [0, 0, 1.5, 0.4]], np.float32)  # rotation + non-uniform scale
+    box = scenes.cornell_box(tall_kind=1, short_kind=3)
+    multi = R.Scene([knot, box.meshes[0]],
+                    [R.Instance(R.IDENTITY, 0, 1), R.Instance(rot, 0, 0), R.Instance(R.IDENTITY, 1, 0),
+                     R.Instance(np.array([[0.3, 0, 0, -0.5], [0, 0.3, 0, 0.5], [0, 0, 0.3, 0.2]], np.float32), 0, 3)],
+                    scenes.procedural_sky(32, 16))
+    empty_mesh = R.Mesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
+    with_empty = R.Scene([empty_mesh, knot], [R.Instance(R.IDENTITY, 0, 0), R.Instance(rot, 1, 2)], None)
+    return {"ref4": scenes.ref4_scene(knot, scenes.procedural_sky(32, 16)), "multi": multi, "cornell": box,
+            "with_empty_mesh": with_empty}
+
+
+@pytest.fixture(scope="module", params=sorted(_scenes()))
+def pair(request, ctx, oracle):
+    sc = _scenes()[request.param]
+    dev = R.DeviceScene(ctx, sc, two_level=True)
+    orc = oracle.Scene(*sc.oracle_args(), two_level=True)
+    yield request.param, sc, dev, orc
+    dev.close()
+
+
+def test_hits_match_the_two_level_definition(pair, oracle):
+    name, sc, dev, orc = pair
+    rays = np.concatenate([scenes.random_rays(20000, seed=5), scenes.random_rays(5000, seed=6, radius=0.4)])
+    hits, _ = dev.trace(rays, count=True)
+    ref, _ = orc.intersect(rays, use_bvh=False)
+    assert np.array_equal(hits["flat"], ref["id"]), name
+    hit = ref["id"] != oracle.NO_HIT
+    assert hit.any()
+    for k in ("t", "u", "v"):
+        assert np.array_equal(_bits(hits[k][hit]), _bits(ref[k][hit])), (name, k)
+    assert dev.info.n_triangles == sc.n_triangles  # ids stay flattened ids
+
+
+def test_agrees_with_the_flattened_scene_up_to_rounding(pair, ctx):
+    name, sc, dev, orc = pair
+    flat = R.DeviceScene(ctx, sc)
+    rays = scenes.random_rays(20000, seed=8)
+    a = dev.trace(rays)
+    b = flat.trace(rays)
+    same = a["flat"] == b["flat"]
+    assert same.mean() > 0.999, name
+    both = same & (a["flat"] != 0xFFFFFFFF)
+    assert np.allclose(a["t"][both], b["t"][both], rtol=1e-4, atol=1e-5)
+    # memory does not grow with the instance count
+    n_mesh_tris = sum(m.indices.shape[0] for m in sc.meshes)
+    if sc.n_triangles > n_mesh_tris:
+        assert dev.info.device_bytes < flat.info.device_bytes
+    flat.close()
+
+
+@pytest.mark.parametrize("integrator", [R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM],
+                         ids=["megakernel", "wavefront", "stream"])
+def test_render_bit_exact(pair, ctx, oracle, integrator):
+    name, sc, dev, orc = pair
+    w, h = 44, 26
+    cam = R.default_camera(w, h)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.max_depth = 6
+    rr.integrator = integrator
+    rr.render(cam, frame=3, n_frames=2)
+    rr.render(cam, frame=5, samples_per_frame=2, n_frames=1)
+    ref_acc, _, _ = orc.render(oracle.make_push(cam.as_dict(), frame=3), w, h, n_frames=2, max_depth=6, use_bvh=False)
+    push = oracle.make_push(cam.as_dict(), frame=5, sample_count=2, samples_per_frame=2)
+    ref_acc, ref_img, _ = orc.render(push, w, h, accum=ref_acc, n_frames=1, max_depth=6, use_bvh=False)
+    assert np.array_equal(_bits(rr.read_accum()), _bits(ref_acc)), name
+    assert np.array_equal(rr.read_rgba8(), ref_img), name
+    ids = dev.primary_hits(cam, w, h, 3)
+    ref_ids = orc.primary_hits(oracle.make_push(cam.as_dict(), frame=3), w, h, use_bvh=False)
+    assert np.array_equal(ids, ref_ids), name
+    rr.close()
+
+
+def test_instance_limit(ctx):
+    box = scenes.cornell_box()
+    many = R.Scene([box.meshes[0]], [R.Instance(R.IDENTITY, 0, 0)] * 1025, None)
+    with pytest.raises(R.PtcError, match="too many instances"):
+        R.DeviceScene(ctx, many, two_level=True)
