@@ -969,12 +969,14 @@ PTC_DEV Hit trace_two_level(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *
     return best;
 }
 
-// The closest-hit query of whichever kind the scene was built for.
-template <bool kCount, int kLds = kLdsStack>
+// The closest-hit query of the kind the scene was built for. (A compile-time
+// choice: kernels are instantiated for both kinds and picked by the host, so
+// the flattened path carries none of the other's registers or code.)
+template <bool kCount, bool kTwoLevel, int kLds = kLdsStack>
 PTC_DEV Hit trace_scene(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_stack, uint32_t stride,
                         TraceCounters *ctr)
 {
-    if (S.inst_box != nullptr)
+    if (kTwoLevel)
     {
         return trace_two_level<kCount, kLds>(S, o, d, tmax, lds_stack, stride, ctr);
     }
@@ -984,7 +986,7 @@ PTC_DEV Hit trace_scene(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_
 
 // ---- path loop: shader.rgen:60-100 -------------------------------------------
 
-template <bool kCount>
+template <bool kCount, bool kTwoLevel>
 PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, vec3 origin, vec3 dir, uint32_t &rng_io, uint2 *lds_stack,
                       uint32_t stride, uint32_t &rays, TraceCounters *ctr)
 {
@@ -997,7 +999,7 @@ PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, vec3 origin, vec3 dir, u
     for (uint32_t bounces = 0; bounces < f.max_depth; ++bounces)
     {
         // counting runs use the reproducible visit order, plain runs the faster one
-        const Hit h = trace_scene<kCount>(S, ps.origin, ps.dir, f.tmax, lds_stack, stride, ctr);
+        const Hit h = trace_scene<kCount, kTwoLevel>(S, ps.origin, ps.dir, f.tmax, lds_stack, stride, ctr);
         ++rays;
         if (!path_bounce(S, h, ps))
         {

@@ -21,7 +21,7 @@ PTC_DEV unsigned long long wave_sum_u64(unsigned long long v)
 
 // One lane owns one pixel and walks all of its samples for all dispatches of
 // this call. A wave covers an 8x8 pixel tile, a block a 16x16 tile.
-template <bool kCount>
+template <bool kCount, bool kTwoLevel>
 __global__ void __launch_bounds__(kBlock)
 k_render_mega(DScene S, DFrame F, float4 *__restrict__ accum, uint32_t *__restrict__ rgba8,
               DeviceStats *__restrict__ stats)
@@ -55,7 +55,7 @@ k_render_mega(DScene S, DFrame F, float4 *__restrict__ accum, uint32_t *__restri
             {
                 vec3 origin, dir;
                 camera_ray(F, px, py, rng, origin, dir);
-                const vec3 c = radiance<kCount>(S, F, origin, dir, rng, stack, kBlock, rays, &ctr);
+                const vec3 c = radiance<kCount, kTwoLevel>(S, F, origin, dir, rng, stack, kBlock, rays, &ctr);
                 ++paths;
                 acc.x += c.x;
                 acc.y += c.y;
@@ -104,7 +104,9 @@ k_primary_hits(DScene S, DFrame F, uint32_t *__restrict__ ids)
     uint32_t rng = seed_(i, F.global_frame_count);
     vec3 o, d;
     camera_ray(F, px, py, rng, o, d);
-    const Hit h = trace_scene<false>(S, o, d, F.tmax, s_stack + threadIdx.x, kBlock, nullptr);
+    const Hit h = S.inst_box != nullptr
+                      ? trace_scene<false, true>(S, o, d, F.tmax, s_stack + threadIdx.x, kBlock, nullptr)
+                      : trace_scene<false, false>(S, o, d, F.tmax, s_stack + threadIdx.x, kBlock, nullptr);
     ids[i] = h.flat;
 }
 
@@ -200,15 +202,17 @@ int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
 {
     const uint32_t tiles = ((F.width + 15u) >> 4) * ((F.height + 15u) >> 4);
     PhaseTimer timer(ctx, PTC_PHASE_MEGAKERNEL);
+    const bool two_level = scene->d.inst_box != nullptr;
+    auto launch = [&](auto kernel) {
+        kernel<<<tiles, kBlock, 0, ctx->stream>>>(scene->d, F, film->d_accum, film->d_rgba8, ctx->d_stats);
+    };
     if (count)
     {
-        k_render_mega<true><<<tiles, kBlock, 0, ctx->stream>>>(scene->d, F, film->d_accum, film->d_rgba8,
-                                                              ctx->d_stats);
+        two_level ? launch(k_render_mega<true, true>) : launch(k_render_mega<true, false>);
     }
     else
     {
-        k_render_mega<false><<<tiles, kBlock, 0, ctx->stream>>>(scene->d, F, film->d_accum,
-                                                               film->d_rgba8, ctx->d_stats);
+        two_level ? launch(k_render_mega<false, true>) : launch(k_render_mega<false, false>);
     }
     PTC_HIP_CHECK(hipGetLastError());
     return PTC_OK;

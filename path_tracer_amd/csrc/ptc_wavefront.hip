@@ -134,7 +134,7 @@ PTC_DEV PathState camera_path(const DFrame &F, uint32_t px, uint32_t py, uint32_
 }
 
 constexpr int kPrimaryLds = 8; // LDS stack entries per lane: 16 KB per block, so registers (not LDS) set the occupancy
-template <bool kPixelMajor>
+template <bool kPixelMajor, bool kTwoLevel>
 __global__ void __launch_bounds__(kBlock)
 k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample,
              uint32_t n_disp, uint32_t lane_bits)
@@ -197,8 +197,8 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
         alive = F.max_depth > 0u;
         if (alive)
         {
-            const Hit h = trace_scene<false, kPrimaryLds>(S, ps.origin, ps.dir, F.tmax, s_stack + threadIdx.x,
-                                                          kBlock, nullptr);
+            const Hit h = trace_scene<false, kTwoLevel, kPrimaryLds>(S, ps.origin, ps.dir, F.tmax,
+                                                                     s_stack + threadIdx.x, kBlock, nullptr);
             alive = path_bounce(S, h, ps) && F.max_depth > 1u;
         }
         if (!alive)
@@ -243,8 +243,10 @@ k_wf_trace(DScene S, float tmax, WfState q, float4 *__restrict__ hit, uint2 *__r
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
     {
         const float4 a = q.a[i], b = q.b[i];
-        const Hit h = trace_scene<false>(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), tmax, s_stack + threadIdx.x,
-                                         kBlock, nullptr);
+        const vec3 o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
+        const Hit h = S.inst_box != nullptr
+                          ? trace_scene<false, true>(S, o, d, tmax, s_stack + threadIdx.x, kBlock, nullptr)
+                          : trace_scene<false, false>(S, o, d, tmax, s_stack + threadIdx.x, kBlock, nullptr);
         hit[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.flat));
         hit_ids[i] = make_uint2(h.instance, h.primitive);
     }
@@ -679,13 +681,29 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
                 {
                     const uint32_t pixel_blocks = (tiles * 256u) / (kBlock >> lane_bits);
                     const uint32_t k_groups = (nb + (1u << lane_bits) - 1u) >> lane_bits;
-                    k_wf_primary<true><<<pixel_blocks * k_groups, kBlock, 0, st>>>(
-                        scene->d, F0, B, F0.global_frame_count, k0, s, nb, lane_bits);
+                    if (two_level)
+                    {
+                        k_wf_primary<true, true><<<pixel_blocks * k_groups, kBlock, 0, st>>>(
+                            scene->d, F0, B, F0.global_frame_count, k0, s, nb, lane_bits);
+                    }
+                    else
+                    {
+                        k_wf_primary<true, false><<<pixel_blocks * k_groups, kBlock, 0, st>>>(
+                            scene->d, F0, B, F0.global_frame_count, k0, s, nb, lane_bits);
+                    }
                 }
                 else
                 {
-                    k_wf_primary<false><<<tiles * nb, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0,
-                                                                      s, nb, 0u);
+                    if (two_level)
+                    {
+                        k_wf_primary<false, true><<<tiles * nb, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count,
+                                                                                k0, s, nb, 0u);
+                    }
+                    else
+                    {
+                        k_wf_primary<false, false><<<tiles * nb, kBlock, 0, st>>>(scene->d, F0, B,
+                                                                                 F0.global_frame_count, k0, s, nb, 0u);
+                    }
                 }
             }
             const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_paths + kBlock - 1) / kBlock);
