@@ -99,7 +99,7 @@ int main(int argc, char **argv)
         std::string out = "render.png", env;
         std::uint32_t width = 640, height = 480, spp = 64, spf = 1, depth = 32; // src/application.cpp:206-207
         int device = 0;
-        bool megakernel = false;
+        bool megakernel = false, two_level = false;
         for (int i = 1; i < argc; ++i)
         {
             const std::string a = argv[i];
@@ -119,10 +119,11 @@ int main(int argc, char **argv)
             else if (a == "--env") env = next();
             else if (a == "--device") device = std::atoi(next());
             else if (a == "--megakernel") megakernel = true;
+            else if (a == "--two-level") two_level = true;
             else if (a[0] == '-')
             {
                 std::cerr << "Usage: " << argv[0] << " [<file.obj|.ply>] [--width W] [--height H] [--spp N] [--spf N] "
-                          << "[--depth D] [--megakernel] [--env sky.hdr] [--out image.png] [--device N]\n";
+                          << "[--depth D] [--megakernel] [--two-level] [--env sky.hdr] [--out image.png] [--device N]\n";
                 return EXIT_FAILURE;
             }
             else file = argv[i];
@@ -151,7 +152,9 @@ int main(int argc, char **argv)
         }
 
         Render_context context = create_context(device);
-        Render_resources rr = create_render_resources(context, width, height, scene);
+        ptc_build_options build {};
+        build.two_level = two_level ? 1u : 0u;
+        Render_resources rr = create_render_resources(context, width, height, scene, &build);
         rr.samples_to_render = spp;
         rr.samples_per_frame = spf;
         rr.max_depth = depth;

@@ -201,11 +201,15 @@ struct Image_f32
     return ctx;
 }
 
-// create_render_resources (src/renderer.cpp:1738-1955)
+// create_render_resources (src/renderer.cpp:1738-1955). build_options->two_level
+// keeps one tree per mesh plus an instance list, the shape of the reference's
+// acceleration structures (src/renderer.cpp:1044-1281), instead of one tree
+// over all instanced triangles.
 [[nodiscard]] inline Render_resources create_render_resources(const Render_context &context,
                                                               std::uint32_t render_width,
                                                               std::uint32_t render_height,
-                                                              const Scene_arrays &scene)
+                                                              const Scene_arrays &scene,
+                                                              const ptc_build_options *build_options = nullptr)
 {
     std::vector<ptc_mesh_desc> meshes;
     for (const auto &m : scene.meshes)
@@ -225,7 +229,7 @@ struct Image_f32
     rr.height = render_height;
     detail::check(ptc_scene_create(context.handle, meshes.data(), static_cast<std::uint32_t>(meshes.size()),
                                    scene.instances.data(), static_cast<std::uint32_t>(scene.instances.size()),
-                                   &env, nullptr, &rr.scene),
+                                   &env, build_options, &rr.scene),
                   "create_render_resources");
     detail::check(ptc_film_create(context.handle, render_width, render_height, nullptr, nullptr, &rr.film),
                   "create_render_resources");

@@ -54,6 +54,16 @@ def test_obj_file_as_the_reference_scene(tmp_path, ctx):
         rr.render(cam, frame=frame)
     assert np.array_equal(rr.read_rgba8(), img)
     rr.close()
+    # --two-level: one tree for the mesh + four instances; again the mirror's picture
+    png2 = str(tmp_path / "knot2.png")
+    run_cli(str(obj), "--width", "80", "--height", "60", "--spp", "4", "--two-level", "--out", png2)
+    rr = R.create_render_resources(ctx, 80, 60, scenes.ref4_scene(R.import_meshes(str(obj))[0]), two_level=True)
+    for frame in range(4):
+        rr.render(cam, frame=frame)
+    img2 = np.asarray(Image.open(png2))
+    assert np.array_equal(rr.read_rgba8(), img2)
+    rr.close()
+    assert np.mean(img2 != img) < 0.01  # the two hit definitions differ in rounding only
 
 
 def test_env_map_from_hdr_file(tmp_path, ctx):
