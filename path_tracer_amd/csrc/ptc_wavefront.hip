@@ -326,6 +326,16 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     uint32_t mode = kIdle;
     constexpr uint32_t kChunk = 128u; // work items a wave reserves per atomic
     uint32_t chunk_next = 0u, chunk_end = 0u; // this wave's reserved items not handed out yet
+    // The queue is cut into kSegments contiguous segments, each with a head of
+    // its own; a wave pulls from the segment of its XCD first (workgroups are
+    // dealt to the chip's 8 XCDs round-robin) and moves on to the next segment
+    // when that one is used up. Eight heads take an eighth of the same-address
+    // atomics each (the Cornell box, where every path survives and pulls are
+    // frequent, gains 16 %), and one L2 serves paths from one part of the
+    // picture (no measurable effect on the 871k-triangle scene).
+    constexpr uint32_t kSegments = 8u;
+    const uint32_t seg_len = ((n + kSegments * kChunk - 1u) / (kSegments * kChunk)) * kChunk;
+    uint32_t seg = blockIdx.x % kSegments, segs_left = kSegments;
     bool queue_done = n == 0u;                // nothing left to reserve beyond chunk_end
     bool exhausted = n == 0u;
     PathState ps = camera_path(F, 0u, 0u, 0u);
@@ -390,18 +400,27 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             // atomic: one atomic per pull would bound the whole kernel.) A pull
             // that the rest of the chunk cannot serve fully leaves the other
             // lanes idle until the next pull.
-            if (chunk_next == chunk_end)
+            while (chunk_next == chunk_end && !queue_done)
             {
                 const uint32_t leader = (uint32_t)__builtin_ctzll(need);
                 uint32_t fresh = 0;
                 if (lane == leader)
                 {
-                    fresh = atomicAdd(head, kChunk);
+                    fresh = atomicAdd(head + seg, kChunk);
                 }
                 fresh = __shfl(fresh, (int)leader, 64);
-                chunk_next = fresh < n ? fresh : n;
-                chunk_end = fresh + kChunk < n ? fresh + kChunk : n;
-                queue_done = fresh + kChunk >= n;
+                const uint32_t lo = seg * seg_len;
+                const uint32_t hi = lo + seg_len < n ? lo + seg_len : n;
+                if (lo < hi && fresh < hi - lo)
+                {
+                    chunk_next = lo + fresh;
+                    chunk_end = chunk_next + kChunk < hi ? chunk_next + kChunk : hi;
+                }
+                else
+                {
+                    seg = (seg + 1u) % kSegments;
+                    queue_done = --segs_left == 0u;
+                }
             }
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t rank = (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
@@ -600,7 +619,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
         1u, std::min<uint64_t>(F0.n_frames,
                                F0.max_paths_in_flight / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
     const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
-    const size_t n_counts = (size_t)F0.max_depth + 2;
+    const size_t n_counts = (size_t)F0.max_depth + 1 + 8; // live paths per bounce, then the drain's queue heads
     // stream mode keeps live paths in registers: only the radiance array is needed
     const size_t qcap = stream ? 1 : cap;
     const size_t bytes = 2 * (align256(qcap * 16) * 3 + align256(qcap * 8)) + align256(qcap * 16) + align256(qcap * 8) +
