@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--save-png", default="")
     ap.add_argument("--wavefront-bounces", type=int, default=0)
     ap.add_argument("--search-radius", type=int, default=0)
+    ap.add_argument("--two-level", action="store_true",
+                    help="one tree per mesh + instance list instead of one tree over all instanced triangles")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +129,7 @@ def main():
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     torch.cuda.synchronize()
     rr = R.create_render_resources(ctx, W, H, scene, accum_dev=accum.data_ptr(),
-                                   search_radius=args.search_radius)
+                                   search_radius=args.search_radius, two_level=args.two_level)
     rr.max_depth = args.max_depth
     rr.accumulate = R.ACCUM_SUM
     rr.integrator = R.INTEGRATOR_WAVEFRONT if args.integrator == "wavefront" else R.INTEGRATOR_MEGAKERNEL
@@ -238,7 +240,8 @@ def main():
             "reduce_ms": None if reduce_ms is None else round(reduce_ms, 3),
             "rays_per_path": round(total_rays / max(total_paths, 1.0), 3),
             "config": {"workload": f"{scene_desc}; {W}x{H}, {spp} spp per GPU per step, "
-                                   f"max depth {args.max_depth}, {args.integrator}, spp sharded "
+                                   f"max depth {args.max_depth}, {args.integrator}"
+                                   f"{', two-level scene' if args.two_level else ''}, spp sharded "
                                    f"over {world} GPU(s), RCCL sum at the end",
                        "triangles": info.n_triangles, "bvh_nodes": info.n_nodes,
                        "bvh_build_ms": round(info.build_ms, 2), "bvh_sah_cost": round(info.sah_cost, 2)},

@@ -929,23 +929,28 @@ PTC_DEV Hit trace_closest_interleaved(const DScene &S, vec3 o, vec3 d, float tma
 // larger flattened indices, so the strict t < limit of the triangle test is
 // exactly the (t, flat) order of the hit definition. The list is linear: the
 // reference's instance counts are a handful.
+// Conservative slab test of a ray against the padded world box of an instance.
+PTC_DEV bool ray_meets_instance_box(const DScene &S, uint32_t i, vec3 o, vec3 d, float best_t)
+{
+    const float idx = 1.0f / clamp_dir(d.x), idy = 1.0f / clamp_dir(d.y), idz = 1.0f / clamp_dir(d.z);
+    const float4 lo = S.inst_box[2u * i], hi = S.inst_box[2u * i + 1u];
+    const float ax = (lo.x - o.x) * idx, bx = (hi.x - o.x) * idx;
+    const float ay = (lo.y - o.y) * idy, by = (hi.y - o.y) * idy;
+    const float az = (lo.z - o.z) * idz, bz = (hi.z - o.z) * idz;
+    const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
+    const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
+    const float slack = (__builtin_fabsf(tn) + __builtin_fabsf(tf)) * kSlabSlack;
+    return tn - slack <= tf + slack && tf + slack >= 0.0f && tn - slack <= best_t * kTLimitPad;
+}
+
 template <bool kCount, int kLds = kLdsStack>
 PTC_DEV Hit trace_two_level(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_stack, uint32_t stride,
                             TraceCounters *ctr)
 {
     Hit best = no_hit(tmax);
-    const float idx = 1.0f / clamp_dir(d.x), idy = 1.0f / clamp_dir(d.y), idz = 1.0f / clamp_dir(d.z);
     for (uint32_t i = 0; i < S.n_instances; ++i)
     {
-        // conservative slab test against the (padded) world box
-        const float4 lo = S.inst_box[2u * i], hi = S.inst_box[2u * i + 1u];
-        const float ax = (lo.x - o.x) * idx, bx = (hi.x - o.x) * idx;
-        const float ay = (lo.y - o.y) * idy, by = (hi.y - o.y) * idy;
-        const float az = (lo.z - o.z) * idz, bz = (hi.z - o.z) * idz;
-        const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
-        const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
-        const float slack = (__builtin_fabsf(tn) + __builtin_fabsf(tf)) * kSlabSlack;
-        if (!(tn - slack <= tf + slack) || !(tf + slack >= 0.0f) || !(tn - slack <= best.t * kTLimitPad))
+        if (!ray_meets_instance_box(S, i, o, d, best.t))
         {
             continue;
         }

@@ -289,6 +289,21 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
     }
 }
 
+// One triangle test of the persistent kernel. In a two-level scene the records
+// of a mesh's tree carry no instance: a test that improved the hit marks it
+// with the instance the lane is in.
+template <bool kTwoLevel>
+PTC_DEV void drain_tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index, uint32_t inst, Hit &best)
+{
+    const float t0 = best.t;
+    const uint32_t f0 = best.flat;
+    tri_test(S, R, tri_index, best);
+    if (kTwoLevel)
+    {
+        best.instance = (best.t != t0 || best.flat != f0) ? inst : best.instance;
+    }
+}
+
 // Finishes every path still alive at `bounce` in one launch. Once few paths are
 // left, a launch pair per bounce costs more in launch latency than in work, so
 // the tail runs persistent: each lane pulls a live path from the queue (one
@@ -303,7 +318,7 @@ constexpr int kDrainLds = 16; // LDS stack entries per lane in the drain kernel 
 // a wave that pulls 64 items at once gets one coherent tile; the
 // samples_per_frame samples of an item run back to back in the same lane on
 // one RNG stream, as shader.rgen:179 does.
-template <bool kCamera>
+template <bool kCamera, bool kTwoLevel>
 __global__ void __launch_bounds__(kBlock, 4)
 k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t n_items, uint32_t n_disp,
            uint32_t k_first, uint32_t *__restrict__ head, DeviceStats *__restrict__ stats)
@@ -346,6 +361,12 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     uint2 *const lds = s_stack + threadIdx.x;
     uint2 spill[kStackTotal - kDrainLds];
     int sp = 0;
+    // Two-level scenes: the instance whose tree the lane is in. R is then the
+    // ray in that instance's object space, best.flat the primitive index within
+    // the instance's mesh (a tie in t can only occur inside one instance: later
+    // instances start with the best t so far as their strict limit, which is the
+    // (t, flattened index) order because flattened indices grow with the instance).
+    uint32_t inst = 0u;
     for (;;)
     {
         const unsigned long long trav = __ballot(mode == kTrav);
@@ -358,6 +379,11 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
         {
             if (mode == kShade)
             {
+                if (kTwoLevel && best.flat != kNoHit)
+                {
+                    best.primitive = best.flat;
+                    best.flat += S.instances[best.instance].first_flat;
+                }
                 const bool alive = path_bounce(S, best, ps) && (bounce + 1u) < max_depth;
                 ++bounce;
                 if (alive)
@@ -455,9 +481,17 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
         }
         if (start)
         {
-            R = make_ray_ctx(ps.origin, ps.dir, tmax);
             best = no_hit(tmax);
-            ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
+            if (kTwoLevel)
+            {
+                inst = 0xffffffffu; // the first instance is looked for below
+                ng = make_uint2(0u, 0u);
+            }
+            else
+            {
+                R = make_ray_ctx(ps.origin, ps.dir, tmax);
+                ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
+            }
             tg = make_uint2(0u, 0u);
             sp = 0;
             mode = kTrav;
@@ -473,6 +507,25 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             if (sp == 0)
             {
                 mode = kShade;
+                if (kTwoLevel)
+                {
+                    // on to the next instance whose world box the ray meets
+                    uint32_t root = kNoBlas;
+                    while (root == kNoBlas && ++inst < S.n_instances)
+                    {
+                        if (ray_meets_instance_box(S, inst, ps.origin, ps.dir, best.t))
+                        {
+                            root = S.instances[inst].blas_root;
+                        }
+                    }
+                    if (root != kNoBlas)
+                    {
+                        const DInstance *__restrict__ I = &S.instances[inst];
+                        R = make_ray_ctx(xform_point(I->w2o, ps.origin), xform_vector(I->w2o, ps.dir), best.t);
+                        ng = make_uint2(root, 0x80000000u);
+                        mode = kTrav;
+                    }
+                }
             }
             else
             {
@@ -507,7 +560,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
         {
             const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
             tg.y &= tg.y - 1u;
-            tri_test(S, R, tg.x + i, best);
+            drain_tri_test<kTwoLevel>(S, R, tg.x + i, inst, best);
         }
         // When many lanes of the wave still have triangles pending (scenes with
         // few, large leaves are bound by this), they test one more right away.
@@ -518,7 +571,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             {
                 const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
                 tg.y &= tg.y - 1u;
-                tri_test(S, R, tg.x + i, best);
+                drain_tri_test<kTwoLevel>(S, R, tg.x + i, inst, best);
             }
         }
     }
@@ -609,11 +662,8 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     hipStream_t st = ctx->stream;
     const uint32_t n_pixels = F0.width * F0.height;
     const uint32_t spf = F0.samples_per_frame;
-    // the persistent kernel walks one flattened tree: two-level scenes run every
-    // bounce as a traversal / shading launch pair instead
     const bool two_level = scene->d.inst_box != nullptr;
-    const uint32_t wf_bounces = two_level ? F0.max_depth : F0.wavefront_bounces;
-    stream = stream && !two_level;
+    const uint32_t wf_bounces = F0.wavefront_bounces;
     // dispatches per batch: bounded so the workspace stays bounded (by default 2^27 paths, about 21 GB)
     const uint32_t max_batch = std::max<uint32_t>(
         1u, std::min<uint64_t>(F0.n_frames,
@@ -673,8 +723,16 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             {
                 PhaseTimer timer(ctx, PTC_PHASE_DRAIN);
                 const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_items + kBlock - 1) / kBlock);
-                k_wf_drain<true><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, 0u, 0, n_items, nb, k0,
-                                                           B.counts + (F0.max_depth + 1u), ctx->d_stats);
+                if (two_level)
+                {
+                    k_wf_drain<true, true><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, 0u, 0, n_items, nb, k0,
+                                                                     B.counts + (F0.max_depth + 1u), ctx->d_stats);
+                }
+                else
+                {
+                    k_wf_drain<true, false><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, 0u, 0, n_items, nb, k0,
+                                                                      B.counts + (F0.max_depth + 1u), ctx->d_stats);
+                }
             }
             k_wf_stats<<<1, 64, 0, st>>>(B.counts, n_paths * spf, 0u, 1u, ctx->d_stats);
         }
@@ -739,8 +797,18 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             if (drain_b < F0.max_depth)
             {
                 PhaseTimer timer(ctx, PTC_PHASE_DRAIN);
-                k_wf_drain<false><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, drain_b, (int)(drain_b & 1u), 0u, 0u, 0u,
-                                                            B.counts + (F0.max_depth + 1u), ctx->d_stats);
+                if (two_level)
+                {
+                    k_wf_drain<false, true><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, drain_b, (int)(drain_b & 1u), 0u,
+                                                                      0u, 0u, B.counts + (F0.max_depth + 1u),
+                                                                      ctx->d_stats);
+                }
+                else
+                {
+                    k_wf_drain<false, false><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, drain_b, (int)(drain_b & 1u), 0u,
+                                                                       0u, 0u, B.counts + (F0.max_depth + 1u),
+                                                                       ctx->d_stats);
+                }
             }
             k_wf_stats<<<1, 64, 0, st>>>(B.counts, n_paths, F0.max_depth, drain_b, ctx->d_stats);
         }
