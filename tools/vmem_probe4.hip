@@ -149,6 +149,13 @@ int main()
         const uint32_t c2 = run<2>("C dealt, direct to LDS", tab, 130603, a, out, h_out);
         if (c0 != c1 || c0 != c2) printf("   MISMATCH\n");
     }
+    // the three forms again on tables that fit L2
+    for (uint32_t n : {8192u, 32768u})
+    {
+        run<0>("A per-lane", tab, n, 37, out, h_out);
+        run<1>("B dealt, via registers", tab, n, 37, out, h_out);
+        run<2>("C dealt, direct to LDS", tab, n, 37, out, h_out);
+    }
     // table size and record alignment (form A, 37 lanes): 80-byte records packed, or one per 128-byte line
     for (uint32_t n : {8192u, 32768u, 130603u, 524288u, 1048576u})
     {
