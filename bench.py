@@ -51,6 +51,13 @@ def build_scene(name: str, env_res: int):
         from path_tracer_amd.renderer import IDENTITY, Instance, Scene
         return (Scene([scenes.torus_mesh(3162, 1581)], [Instance(IDENTITY, 0, 0)], sky),
                 "fractal torus, 9,998,244 triangles, diffuse")
+    if os.path.isfile(name):
+        # a mesh file (OBJ / PLY, e.g. the real dragon_vrip.ply where it is at hand): mesh 0, imported with
+        # the reference's post-processing steps, as the one specular instance of the headline configuration
+        from path_tracer_amd.renderer import IDENTITY, KIND_SPECULAR, Instance, Scene, import_meshes
+        mesh = import_meshes(name)[0]
+        return (Scene([mesh], [Instance(IDENTITY, 0, KIND_SPECULAR)], sky),
+                f"{os.path.basename(name)}: {mesh.indices.shape[0]:,} triangles, specular, procedural sky")
     raise SystemExit(f"unknown scene {name}")
 
 
@@ -89,7 +96,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-step", type=int, default=64)
-    ap.add_argument("--scene", default="dragon")
+    ap.add_argument("--scene", default="dragon",
+                    help="dragon | ref4 | cornell | torus10m | dragon_small | path of an OBJ / PLY file")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-depth", type=int, default=32)
