@@ -916,6 +916,8 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
 
     uint32_t n_nodes = 1, depth = 1;
     double root_half_area = 0.0;
+    scene->d.box_lo = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    scene->d.box_hi = make_float4(-1.0f, -1.0f, -1.0f, 0.0f);
     if (n == 0)
     {
         PTC_HIP_CHECK(hipMemsetAsync(nodes_tmp, 0, 80, st));
@@ -1031,6 +1033,9 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
             PTC_HIP_CHECK(hipStreamSynchronize(st));
             const double dx = (double)rh.x - rl.x, dy = (double)rh.y - rl.y, dz = (double)rh.z - rl.z;
             root_half_area = dx * dy + dy * dz + dz * dx;
+            // union of the padded triangle boxes
+            scene->d.box_lo = make_float4(rl.x, rl.y, rl.z, 0.0f);
+            scene->d.box_hi = make_float4(rh.x, rh.y, rh.z, 0.0f);
         }
         uint32_t level_start = 0, level_end = 1, tri_alloc = 0;
         depth = 0;

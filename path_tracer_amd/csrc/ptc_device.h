@@ -37,6 +37,9 @@ struct DScene
     // instance, (lo, hi) pairs; nodes / tris then hold one tree per mesh in
     // object space and rays enter an instance through its w2o matrix
     const float4 *__restrict__ inst_box;
+    // flattened scenes: the (padded) box of the whole tree, for rays that start
+    // outside it; lo > hi when the scene has no triangles
+    float4 box_lo, box_hi;
     const float4 *__restrict__ env; // RGBA32F equirect map or nullptr
     uint32_t env_w, env_h;
     uint32_t n_instances;
@@ -929,11 +932,10 @@ PTC_DEV Hit trace_closest_interleaved(const DScene &S, vec3 o, vec3 d, float tma
 // larger flattened indices, so the strict t < limit of the triangle test is
 // exactly the (t, flat) order of the hit definition. The list is linear: the
 // reference's instance counts are a handful.
-// Conservative slab test of a ray against the padded world box of an instance.
-PTC_DEV bool ray_meets_instance_box(const DScene &S, uint32_t i, vec3 o, vec3 d, float best_t)
+// Conservative slab test of a ray against a padded box.
+PTC_DEV bool ray_meets_box(float4 lo, float4 hi, vec3 o, vec3 d, float best_t)
 {
     const float idx = 1.0f / clamp_dir(d.x), idy = 1.0f / clamp_dir(d.y), idz = 1.0f / clamp_dir(d.z);
-    const float4 lo = S.inst_box[2u * i], hi = S.inst_box[2u * i + 1u];
     const float ax = (lo.x - o.x) * idx, bx = (hi.x - o.x) * idx;
     const float ay = (lo.y - o.y) * idy, by = (hi.y - o.y) * idy;
     const float az = (lo.z - o.z) * idz, bz = (hi.z - o.z) * idz;
@@ -941,6 +943,11 @@ PTC_DEV bool ray_meets_instance_box(const DScene &S, uint32_t i, vec3 o, vec3 d,
     const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
     const float slack = (__builtin_fabsf(tn) + __builtin_fabsf(tf)) * kSlabSlack;
     return tn - slack <= tf + slack && tf + slack >= 0.0f && tn - slack <= best_t * kTLimitPad;
+}
+
+PTC_DEV bool ray_meets_instance_box(const DScene &S, uint32_t i, vec3 o, vec3 d, float best_t)
+{
+    return ray_meets_box(S.inst_box[2u * i], S.inst_box[2u * i + 1u], o, d, best_t);
 }
 
 template <bool kCount, int kLds = kLdsStack>

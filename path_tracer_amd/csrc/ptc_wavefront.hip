@@ -197,8 +197,15 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
         alive = F.max_depth > 0u;
         if (alive)
         {
-            const Hit h = trace_scene<false, kTwoLevel, kPrimaryLds>(S, ps.origin, ps.dir, F.tmax,
-                                                                     s_stack + threadIdx.x, kBlock, nullptr);
+            // Camera rays start outside the scene more often than not: one box
+            // test spares those the visit of the root node. (A wave holds samples
+            // of one pixel or of one tile, so its lanes mostly agree.)
+            Hit h = no_hit(F.tmax);
+            if (kTwoLevel || ray_meets_box(S.box_lo, S.box_hi, ps.origin, ps.dir, F.tmax))
+            {
+                h = trace_scene<false, kTwoLevel, kPrimaryLds>(S, ps.origin, ps.dir, F.tmax, s_stack + threadIdx.x,
+                                                               kBlock, nullptr);
+            }
             alive = path_bounce(S, h, ps) && F.max_depth > 1u;
         }
         if (!alive)
