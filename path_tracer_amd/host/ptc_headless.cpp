@@ -98,6 +98,7 @@ int main(int argc, char **argv)
         const char *file = nullptr;
         std::string out = "render.png", env;
         std::uint32_t width = 640, height = 480, spp = 64, spf = 1, depth = 32; // src/application.cpp:206-207
+        std::uint32_t preview_every = 0;
         int device = 0;
         bool megakernel = false, two_level = false;
         for (int i = 1; i < argc; ++i)
@@ -120,10 +121,11 @@ int main(int argc, char **argv)
             else if (a == "--device") device = std::atoi(next());
             else if (a == "--megakernel") megakernel = true;
             else if (a == "--two-level") two_level = true;
+            else if (a == "--preview-every") preview_every = std::strtoul(next(), nullptr, 10);
             else if (a[0] == '-')
             {
                 std::cerr << "Usage: " << argv[0] << " [<file.obj|.ply>] [--width W] [--height H] [--spp N] [--spf N] "
-                          << "[--depth D] [--megakernel] [--two-level] [--env sky.hdr] [--out image.png] [--device N]\n";
+                          << "[--depth D] [--megakernel] [--two-level] [--preview-every N] [--env sky.hdr] [--out image.png] [--device N]\n";
                 return EXIT_FAILURE;
             }
             else file = argv[i];
@@ -167,9 +169,24 @@ int main(int argc, char **argv)
                                             static_cast<float>(width) / static_cast<float>(height) * shh, shh);
 
         const auto t0 = std::chrono::steady_clock::now();
+        // The reference shows the target image after every draw_frame()
+        // (src/application.cpp:690-694, :978); without a window the picture so far
+        // is written over the output file every preview_every samples instead.
+        std::uint32_t next_preview = preview_every;
         while (rr.sample_count < rr.samples_to_render)
         {
             draw_frame(context, rr, camera);
+            if (preview_every != 0 && rr.sample_count >= next_preview && rr.sample_count < rr.samples_to_render)
+            {
+                const std::string msg = write_to_png(context, rr, out.c_str());
+                if (!msg.empty())
+                {
+                    std::cerr << msg << '\n';
+                    return EXIT_FAILURE;
+                }
+                std::cout << "preview at " << rr.sample_count << " samples -> " << out << '\n';
+                next_preview = rr.sample_count + preview_every;
+            }
         }
         ptc_synchronize(context.handle);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

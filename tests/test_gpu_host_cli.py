@@ -34,6 +34,15 @@ def test_builtin_scene_both_integrators(tmp_path):
     assert ia[..., :3].std() > 5  # an actual picture, not a constant
 
 
+def test_progressive_preview_does_not_change_the_picture(tmp_path):
+    a, b = str(tmp_path / "plain.png"), str(tmp_path / "preview.png")
+    run_cli("--width", "64", "--height", "48", "--spp", "8", "--spf", "2", "--depth", "4", "--out", a)
+    log = run_cli("--width", "64", "--height", "48", "--spp", "8", "--spf", "2", "--depth", "4", "--preview-every", "2",
+                  "--out", b)
+    assert log.count("preview at") == 3 and "preview at 6 samples" in log  # after 2, 4 and 6 of the 8 samples
+    assert np.array_equal(np.asarray(Image.open(a)), np.asarray(Image.open(b)))
+
+
 def test_obj_file_as_the_reference_scene(tmp_path, ctx):
     m = scenes.knot_mesh(nu=40, nv=10)
     obj = tmp_path / "knot.obj"
