@@ -78,6 +78,27 @@ def test_dragon_1080p_integrators_agree_and_shards_recombine(dragon, ctx):
     assert np.allclose(whole[..., :3] / 4.0, out["wave"][0][..., :3], rtol=1e-5, atol=1e-6)
 
 
+def test_dragon_1080p_whole_bench_step_in_flight(dragon, ctx):
+    """The bench's step: 256 dispatches of the 1080p frame in one launch (2^29
+    paths in flight) give, bit for bit, the film of the same dispatches rendered
+    64 at a time (dispatches are folded into the film in order either way)."""
+    sc, dev, orc = dragon
+    w, h = 1920, 1080
+    cam = R.default_camera(w, h)
+    films = []
+    for in_flight in (256, 64):
+        rr = R.RenderResources(ctx, w, h, dev)
+        rr.accumulate = R.ACCUM_SUM
+        rr.max_paths_in_flight = in_flight * w * h
+        ctx.reset_stats()
+        rr.render(cam, frame=1, n_frames=256, frame_stride=3)
+        films.append((rr.read_accum(), ctx.stats().rays))
+        rr.close()
+    assert films[0][1] == films[1][1] and films[0][1] > 256 * w * h
+    assert np.array_equal(films[0][0].view(np.uint32), films[1][0].view(np.uint32))
+    assert (films[0][0][..., 3] == 256.0).all()
+
+
 def test_ten_million_triangles_build_and_trace(ctx, oracle):
     mesh = scenes.torus_mesh(3162, 1581)
     sc = R.Scene([mesh], [R.Instance(R.IDENTITY, 0, R.KIND_DIFFUSE)], None)
