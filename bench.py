@@ -242,12 +242,13 @@ def main():
         launches_per_step = max(dom_n // max(args.steps, 1), 1)
         avg_ms = dom_ms / max(dom_n, 1)
         achieved = alg_bytes / launches_per_step / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else float("nan")
-        traffic = None
+        traffic = l2_hit = None
         tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("kernel") == dom and tj.get("spp_per_step") == spp and tj.get("scene") == args.scene:
                 traffic = tj.get("hbm_bytes_per_launch")
+                l2_hit = round(tj["l2_hit_rate"], 3) if "l2_hit_rate" in tj else None
         out = {
             "metric": "Mrays/s (whole node), dragon 1080p", "value": round(total_rays / elapsed / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -264,6 +265,7 @@ def main():
                        "bvh_build_ms": round(info.build_ms, 2), "bvh_sah_cost": round(info.sah_cost, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "l2_hit_rate": l2_hit,
                          "kernel": dom, "avg_launch_ms": round(avg_ms, 3),
                          "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": int(alg_bytes / launches_per_step),
