@@ -569,11 +569,16 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             tg.y &= tg.y - 1u;
             drain_tri_test<kTwoLevel>(S, R, tg.x + i, inst, best);
         }
-        // When many lanes of the wave still have triangles pending (scenes with
-        // few, large leaves are bound by this), they test one more right away.
-        const bool more = mode == kTrav && tg.y != 0u;
-        if ((uint32_t)__builtin_popcountll(__ballot(more)) >= kTriMoreMin)
+        // While many lanes of the wave still have triangles pending (scenes with
+        // few, large leaves are bound by this), they test up to three more right
+        // away (more than three gains nothing).
+        for (int extra = 0; extra < 3; ++extra)
         {
+            const bool more = mode == kTrav && tg.y != 0u;
+            if ((uint32_t)__builtin_popcountll(__ballot(more)) < kTriMoreMin)
+            {
+                break;
+            }
             if (more)
             {
                 const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
