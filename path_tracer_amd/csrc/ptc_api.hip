@@ -717,7 +717,7 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
         set_error("ptc_render: samples_per_frame and n_frames must be >= 1");
         return PTC_E_INVALID;
     }
-    if (params->integrator > PTC_INTEGRATOR_STREAM || params->accumulate > PTC_ACCUM_SUM)
+    if (params->integrator > PTC_INTEGRATOR_AUTO || params->accumulate > PTC_ACCUM_SUM)
     {
         set_error("ptc_render: unknown integrator or accumulation mode");
         return PTC_E_INVALID;
@@ -764,9 +764,17 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
     hipEvent_t ev1 = timed ? ctx->ev_pool[ctx->ev_used].second : ctx->ev_stop;
     PTC_HIP_CHECK(hipEventRecord(ev0, ctx->stream));
     int rc;
-    if (params->integrator != PTC_INTEGRATOR_MEGAKERNEL)
+    uint32_t integrator = params->integrator;
+    if (integrator == PTC_INTEGRATOR_AUTO)
     {
-        rc = launch_render_wavefront(ctx, scene, film, F, params->integrator == PTC_INTEGRATOR_STREAM);
+        // dispatches the wavefront integrator would hold in flight per pass
+        const uint64_t per_dispatch = std::max<uint64_t>((uint64_t)F.width * F.height * F.samples_per_frame, 1u);
+        const uint64_t in_flight = std::min<uint64_t>(F.n_frames, std::max<uint64_t>(F.max_paths_in_flight / per_dispatch, 1u));
+        integrator = F.samples_per_frame == 1u || in_flight >= 16u ? PTC_INTEGRATOR_WAVEFRONT : PTC_INTEGRATOR_STREAM;
+    }
+    if (integrator != PTC_INTEGRATOR_MEGAKERNEL)
+    {
+        rc = launch_render_wavefront(ctx, scene, film, F, integrator == PTC_INTEGRATOR_STREAM);
     }
     else
     {

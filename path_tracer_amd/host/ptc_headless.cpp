@@ -160,7 +160,7 @@ int main(int argc, char **argv)
         rr.samples_to_render = spp;
         rr.samples_per_frame = spf;
         rr.max_depth = depth;
-        rr.integrator = megakernel ? PTC_INTEGRATOR_MEGAKERNEL : PTC_INTEGRATOR_WAVEFRONT;
+        rr.integrator = megakernel ? PTC_INTEGRATOR_MEGAKERNEL : PTC_INTEGRATOR_AUTO;
 
         // camera of open_scene(), src/application.cpp:209-222
         const float vertical_fov = 45.0f / 180.0f * 3.14159265358979323846f;

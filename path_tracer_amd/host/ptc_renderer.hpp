@@ -124,7 +124,7 @@ struct Render_resources
     std::uint32_t sample_count {0};
     std::uint32_t samples_per_frame {1};
     std::uint32_t max_depth {32};            // literal of shader.rgen:65
-    std::uint32_t integrator {PTC_INTEGRATOR_WAVEFRONT};
+    std::uint32_t integrator {PTC_INTEGRATOR_AUTO};
     std::uint32_t tonemap {PTC_TONEMAP_PBR_NEUTRAL}; // shader.rgen:218-221
 
     Render_resources() = default;

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libptcore.so")
 
 KIND_DIFFUSE, KIND_SPECULAR, KIND_EMISSIVE, KIND_DIELECTRIC = 0, 1, 2, 3
 TONEMAP_PBR_NEUTRAL, TONEMAP_ACES = 0, 1
-INTEGRATOR_MEGAKERNEL, INTEGRATOR_WAVEFRONT, INTEGRATOR_STREAM = 0, 1, 2
+INTEGRATOR_MEGAKERNEL, INTEGRATOR_WAVEFRONT, INTEGRATOR_STREAM, INTEGRATOR_AUTO = 0, 1, 2, 3
 ACCUM_RUNNING_MEAN, ACCUM_SUM = 0, 1
 NO_HIT = 0xFFFFFFFF
 
@@ -465,7 +465,7 @@ class RenderResources:
         # knobs the reference hard-codes in shader.rgen
         self.max_depth = 32
         self.tmax = 10000.0
-        self.integrator = INTEGRATOR_WAVEFRONT  # like the C++ mirror; all integrators give the same film
+        self.integrator = INTEGRATOR_AUTO  # like the C++ mirror; all integrators give the same film
         self.accumulate = ACCUM_RUNNING_MEAN
         self.instrument = False
         self.wavefront_bounces = 0  # 0 = library default

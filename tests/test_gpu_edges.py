@@ -12,7 +12,7 @@ from path_tracer_amd import scenes
 
 pytestmark = pytest.mark.gpu
 
-INTEGRATORS = [R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM]
+INTEGRATORS = [R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM, R.INTEGRATOR_AUTO]
 
 
 def _bits(a):

@@ -11,7 +11,7 @@ sc = scenes.dragon_scene(envmap=scenes.procedural_sky(2048, 1024))
 W, H = 1920, 1080
 cam = R.default_camera(W, H)
 dev = R.DeviceScene(ctx, sc)
-for spp in (16, 32, 64, 128, 256):
+for spp in (1, 2, 4, 8, 16, 32, 64, 128, 256):
     rr = R.RenderResources(ctx, W, H, dev)
     rr.max_depth = 32
     rr.max_paths_in_flight = min(spp * W * H, 2 ** 32 - 1)
