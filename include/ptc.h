@@ -105,19 +105,15 @@ typedef struct ptc_build_options
     uint32_t search_radius;
     /* 0: every instance's triangles are transformed to world space and go
      * into one tree (fastest traversal; memory grows with the instance count).
-     * 1: one tree per mesh in object space plus a list of instances with
-     * world-space boxes, the structure of the reference's TLAS over one BLAS
-     * (src/renderer.cpp:1044-1281): memory does not grow with the instance
-     * count; a ray enters an instance through its world-to-object matrix, so
-     * hits are computed in object space (they agree with mode 0 up to the
-     * rounding of that transform). At most PTC_MAX_TWO_LEVEL_INSTANCES
-     * instances. The persistent kernels of the wavefront / stream integrators
-     * walk one flattened tree only: two-level scenes render with traversal /
-     * shading launch pairs per bounce or with the megakernel. */
+     * 1: one tree per mesh in object space plus a tree over the world-space
+     * boxes of the instances, the structure of the reference's TLAS over one
+     * BLAS (src/renderer.cpp:1044-1281): memory does not grow with the
+     * triangle count of repeated meshes; a ray enters an instance through its
+     * world-to-object matrix, so hits are computed in object space (they agree
+     * with mode 0 up to the rounding of that transform). */
     uint32_t two_level;
     uint32_t reserved[6];
 } ptc_build_options;
-#define PTC_MAX_TWO_LEVEL_INSTANCES 1024u
 
 typedef struct ptc_scene_info
 {

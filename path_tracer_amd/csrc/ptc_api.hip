@@ -367,11 +367,6 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
             return PTC_E_LIMIT;
         }
     }
-    if (opts && opts->two_level && n_instances > PTC_MAX_TWO_LEVEL_INSTANCES)
-    {
-        set_error("ptc_scene_create: too many instances for a two-level scene");
-        return PTC_E_LIMIT;
-    }
     if (envmap && envmap->rgba && (envmap->width == 0 || envmap->height == 0))
     {
         set_error("ptc_scene_create: empty environment map");

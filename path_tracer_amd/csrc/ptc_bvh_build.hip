@@ -1102,6 +1102,19 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
 
 namespace
 {
+inline uint32_t float_bits(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+inline float bits_float(uint32_t u)
+{
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
 // child and triangle indices of a mesh's tree, moved to where the tree sits in
 // the concatenated arrays
 __global__ void __launch_bounds__(kBlock)
@@ -1227,7 +1240,7 @@ int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &
     // the mesh box through o2w, padded (the box only decides whether the
     // instance is entered, so generous padding costs time, never a hit)
     const size_t n_inst = instances.size();
-    std::vector<float4> boxes(2 * std::max<size_t>(n_inst, 1));
+    std::vector<float4> boxes(2 * n_inst);
     for (size_t i = 0; i < n_inst; ++i)
     {
         DInstance &I = instances[i];
@@ -1259,13 +1272,113 @@ int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &
         boxes[2 * i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         boxes[2 * i + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     }
-    if (e == hipSuccess)
+    // The tree over the instances: those with triangles, sorted along a Morton
+    // curve through their box centres (ties keep the index order), halved
+    // recursively; nodes in depth-first order, each naming the node that follows
+    // its subtree, so the walk needs no stack.
+    std::vector<uint32_t> order;
+    float glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n_inst; ++i)
     {
-        e = hipMalloc(&scene->d_inst_box, boxes.size() * sizeof(float4));
+        if (instances[i].blas_root != kNoBlas)
+        {
+            order.push_back((uint32_t)i);
+            const float c[3] = {0.5f * (boxes[2 * i].x + boxes[2 * i + 1].x), 0.5f * (boxes[2 * i].y + boxes[2 * i + 1].y),
+                                0.5f * (boxes[2 * i].z + boxes[2 * i + 1].z)};
+            for (int r = 0; r < 3; ++r)
+            {
+                glo[r] = std::min(glo[r], c[r]);
+                ghi[r] = std::max(ghi[r], c[r]);
+            }
+        }
+    }
+    auto spread = [](uint32_t v) { // 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000ffu;
+        v = (v | (v << 8)) & 0x0300f00fu;
+        v = (v | (v << 4)) & 0x030c30c3u;
+        v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    };
+    std::vector<uint32_t> code(n_inst, 0u);
+    for (uint32_t i : order)
+    {
+        uint32_t q[3];
+        const float c[3] = {0.5f * (boxes[2 * i].x + boxes[2 * i + 1].x), 0.5f * (boxes[2 * i].y + boxes[2 * i + 1].y),
+                            0.5f * (boxes[2 * i].z + boxes[2 * i + 1].z)};
+        for (int r = 0; r < 3; ++r)
+        {
+            const float ext = ghi[r] - glo[r];
+            const float f = ext > 0.0f ? (c[r] - glo[r]) / ext : 0.0f;
+            q[r] = (uint32_t)std::min(1023.0f, std::max(0.0f, f * 1024.0f));
+        }
+        code[i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+    std::vector<float4> tree;
+    tree.reserve(4 * order.size() + 2);
+    struct Range
+    {
+        uint32_t first, last, node; // instances order[first..last), node already emitted when node != ~0u
+    };
+    // depth-first emission with an explicit stack: a node is emitted when its
+    // range is first met and completed (box, follower) when the range is met again
+    std::vector<Range> todo;
+    if (!order.empty())
+    {
+        todo.push_back({0u, (uint32_t)order.size(), ~0u});
+    }
+    while (!todo.empty())
+    {
+        const Range r = todo.back();
+        todo.pop_back();
+        if (r.node != ~0u)
+        {
+            // both halves are in place behind the node: close it
+            const uint32_t left = r.node + 1u, right = float_bits(tree[2 * (size_t)left].w);
+            float4 lo = tree[2 * (size_t)left], hi = tree[2 * (size_t)left + 1];
+            const float4 rl = tree[2 * (size_t)right], rh = tree[2 * (size_t)right + 1];
+            lo.x = std::min(lo.x, rl.x);
+            lo.y = std::min(lo.y, rl.y);
+            lo.z = std::min(lo.z, rl.z);
+            hi.x = std::max(hi.x, rh.x);
+            hi.y = std::max(hi.y, rh.y);
+            hi.z = std::max(hi.z, rh.z);
+            lo.w = bits_float((uint32_t)(tree.size() / 2));
+            hi.w = bits_float(kNoInstance);
+            tree[2 * (size_t)r.node] = lo;
+            tree[2 * (size_t)r.node + 1] = hi;
+            continue;
+        }
+        const uint32_t node = (uint32_t)(tree.size() / 2);
+        if (r.last - r.first == 1u)
+        {
+            const uint32_t i = order[r.first];
+            float4 lo = boxes[2 * (size_t)i], hi = boxes[2 * (size_t)i + 1];
+            lo.w = bits_float(node + 1u);
+            hi.w = bits_float(i);
+            tree.push_back(lo);
+            tree.push_back(hi);
+            continue;
+        }
+        tree.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        tree.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        const uint32_t mid = r.first + (r.last - r.first) / 2u;
+        todo.push_back({r.first, r.last, node}); // closes the node after its halves
+        todo.push_back({mid, r.last, ~0u});      // right half (emitted second)
+        todo.push_back({r.first, mid, ~0u});     // left half (emitted first, right behind the node)
+    }
+    scene->d.n_inst_nodes = (uint32_t)(tree.size() / 2);
+    if (tree.empty())
+    {
+        tree.resize(2, make_float4(0.0f, 0.0f, 0.0f, 0.0f)); // never read: n_inst_nodes is 0
     }
     if (e == hipSuccess)
     {
-        e = hipMemcpyAsync(scene->d_inst_box, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice, st);
+        e = hipMalloc(&scene->d_inst_box, tree.size() * sizeof(float4));
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMemcpyAsync(scene->d_inst_box, tree.data(), tree.size() * sizeof(float4), hipMemcpyHostToDevice, st);
     }
     if (e == hipSuccess && n_inst)
     {

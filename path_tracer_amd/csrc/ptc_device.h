@@ -24,6 +24,7 @@ struct DInstance // 128 bytes
     uint32_t pad[2];
 };
 constexpr uint32_t kNoBlas = 0xffffffffu;
+constexpr uint32_t kNoInstance = 0xffffffffu;
 
 struct DScene
 {
@@ -33,10 +34,14 @@ struct DScene
     const float *__restrict__ normals;
     const uint32_t *__restrict__ indices; // 3 per triangle, mesh-local vertex ids
     const DInstance *__restrict__ instances;
-    // two-level scenes only (nullptr otherwise): world-space box of every
-    // instance, (lo, hi) pairs; nodes / tris then hold one tree per mesh in
-    // object space and rays enter an instance through its w2o matrix
+    // Two-level scenes only (nullptr otherwise): a binary tree over the world
+    // boxes of the instances, n_inst_nodes nodes in depth-first order, two
+    // float4 each: (box lo, index of the node to go on with when the box is
+    // missed) and (box hi, instance index, or kNoInstance for an inner node).
+    // nodes / tris then hold one tree per mesh in object space and rays enter an
+    // instance through its w2o matrix.
     const float4 *__restrict__ inst_box;
+    uint32_t n_inst_nodes;
     // flattened scenes: the (padded) box of the whole tree, for rays that start
     // outside it; lo > hi when the scene has no triangles
     float4 box_lo, box_hi;
@@ -945,9 +950,39 @@ PTC_DEV bool ray_meets_box(float4 lo, float4 hi, vec3 o, vec3 d, float best_t)
     return tn - slack <= tf + slack && tf + slack >= 0.0f && tn - slack <= best_t * kTLimitPad;
 }
 
-PTC_DEV bool ray_meets_instance_box(const DScene &S, uint32_t i, vec3 o, vec3 d, float best_t)
+// Walks the instance tree from node pos on to the next instance whose box the
+// ray meets; returns its index (kNoInstance: none left) and leaves pos behind it.
+// Needs no stack: a missed node names the node to go on with.
+PTC_DEV uint32_t next_instance(const DScene &S, uint32_t &pos, vec3 o, vec3 d, float best_t)
 {
-    return ray_meets_box(S.inst_box[2u * i], S.inst_box[2u * i + 1u], o, d, best_t);
+    while (pos < S.n_inst_nodes)
+    {
+        const float4 lo = S.inst_box[2u * pos], hi = S.inst_box[2u * pos + 1u];
+        if (ray_meets_box(lo, hi, o, d, best_t))
+        {
+            ++pos;
+            if (__float_as_uint(hi.w) != kNoInstance)
+            {
+                return __float_as_uint(hi.w);
+            }
+        }
+        else
+        {
+            pos = __float_as_uint(lo.w);
+        }
+    }
+    return kNoInstance;
+}
+
+// The t limit of a ray inside instance inst. Instances are met in the tree's
+// order, not in index order, so the (t, instance, primitive) order of the hit
+// definition takes a rule: a hit at exactly the best t wins against a best hit
+// from an instance of larger index (limit one ulp above the best t), and loses
+// against one of smaller index (the strict limit).
+PTC_DEV float instance_t_limit(const Hit &best, uint32_t inst)
+{
+    const bool ties_win = best.flat != kNoHit && inst < best.instance;
+    return ties_win ? __uint_as_float(__float_as_uint(best.t) + 1u) : best.t;
 }
 
 template <bool kCount, int kLds = kLdsStack>
@@ -955,24 +990,19 @@ PTC_DEV Hit trace_two_level(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *
                             TraceCounters *ctr)
 {
     Hit best = no_hit(tmax);
-    for (uint32_t i = 0; i < S.n_instances; ++i)
+    uint32_t pos = 0u;
+    for (uint32_t i = next_instance(S, pos, o, d, best.t); i != kNoInstance;
+         i = next_instance(S, pos, o, d, best.t))
     {
-        if (!ray_meets_instance_box(S, i, o, d, best.t))
-        {
-            continue;
-        }
         const DInstance *__restrict__ I = &S.instances[i];
-        const uint32_t root = I->blas_root;
-        if (root == kNoBlas)
-        {
-            continue;
-        }
         const vec3 ro = xform_point(I->w2o, o);
         const vec3 rd = xform_vector(I->w2o, d);
-        const Hit h = kCount ? trace_closest<true, kLds>(S, ro, rd, best.t, lds_stack, stride, ctr, root)
-                             : trace_closest_interleaved<kLds>(S, ro, rd, best.t, lds_stack, stride, root);
+        const float limit = instance_t_limit(best, i);
+        const Hit h = kCount ? trace_closest<true, kLds>(S, ro, rd, limit, lds_stack, stride, ctr, I->blas_root)
+                             : trace_closest_interleaved<kLds>(S, ro, rd, limit, lds_stack, stride, I->blas_root);
         if (h.flat != kNoHit)
         {
+            // below the limit: nearer than the best so far, or as near in an instance of smaller index
             best = h;
             best.instance = i;
             best.flat = I->first_flat + h.primitive;

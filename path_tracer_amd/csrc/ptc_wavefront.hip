@@ -302,13 +302,25 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
 template <bool kTwoLevel>
 PTC_DEV void drain_tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index, uint32_t inst, Hit &best)
 {
-    const float t0 = best.t;
-    const uint32_t f0 = best.flat;
-    tri_test(S, R, tri_index, best);
-    if (kTwoLevel)
+    if (!kTwoLevel)
     {
-        best.instance = (best.t != t0 || best.flat != f0) ? inst : best.instance;
+        tri_test(S, R, tri_index, best);
+        return;
     }
+    // best.flat counts within its instance's mesh: it decides a tie in t only
+    // against a hit of the same instance. Against another instance's hit, a
+    // tie that got past the ray's t limit wins (see instance_t_limit()).
+    const float t0 = best.t;
+    const uint32_t f0 = best.instance == inst ? best.flat : kNoHit;
+    Hit cand = best;
+    cand.flat = f0;
+    tri_test(S, R, tri_index, cand);
+    const bool improved = cand.t != t0 || cand.flat != f0;
+    best.t = improved ? cand.t : best.t;
+    best.u = improved ? cand.u : best.u;
+    best.v = improved ? cand.v : best.v;
+    best.flat = improved ? cand.flat : best.flat;
+    best.instance = improved ? inst : best.instance;
 }
 
 // Finishes every path still alive at `bounce` in one launch. Once few paths are
@@ -368,12 +380,10 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     uint2 *const lds = s_stack + threadIdx.x;
     uint2 spill[kStackTotal - kDrainLds];
     int sp = 0;
-    // Two-level scenes: the instance whose tree the lane is in. R is then the
-    // ray in that instance's object space, best.flat the primitive index within
-    // the instance's mesh (a tie in t can only occur inside one instance: later
-    // instances start with the best t so far as their strict limit, which is the
-    // (t, flattened index) order because flattened indices grow with the instance).
-    uint32_t inst = 0u;
+    // Two-level scenes: the instance whose tree the lane is in and the lane's
+    // place in the instance tree. R is then the ray in that instance's object
+    // space, best.flat the primitive index within the mesh of best.instance.
+    uint32_t inst = 0u, inst_pos = 0u;
     for (;;)
     {
         const unsigned long long trav = __ballot(mode == kTrav);
@@ -491,7 +501,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             best = no_hit(tmax);
             if (kTwoLevel)
             {
-                inst = 0xffffffffu; // the first instance is looked for below
+                inst_pos = 0u; // the first instance is looked for below
                 ng = make_uint2(0u, 0u);
             }
             else
@@ -517,19 +527,14 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 if (kTwoLevel)
                 {
                     // on to the next instance whose world box the ray meets
-                    uint32_t root = kNoBlas;
-                    while (root == kNoBlas && ++inst < S.n_instances)
+                    const uint32_t next = next_instance(S, inst_pos, ps.origin, ps.dir, best.t);
+                    if (next != kNoInstance)
                     {
-                        if (ray_meets_instance_box(S, inst, ps.origin, ps.dir, best.t))
-                        {
-                            root = S.instances[inst].blas_root;
-                        }
-                    }
-                    if (root != kNoBlas)
-                    {
+                        inst = next;
                         const DInstance *__restrict__ I = &S.instances[inst];
-                        R = make_ray_ctx(xform_point(I->w2o, ps.origin), xform_vector(I->w2o, ps.dir), best.t);
-                        ng = make_uint2(root, 0x80000000u);
+                        R = make_ray_ctx(xform_point(I->w2o, ps.origin), xform_vector(I->w2o, ps.dir),
+                                         instance_t_limit(best, inst));
+                        ng = make_uint2(I->blas_root, 0x80000000u);
                         mode = kTrav;
                     }
                 }

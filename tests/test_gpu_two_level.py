@@ -89,8 +89,78 @@ def test_render_bit_exact(pair, ctx, oracle, integrator):
     rr.close()
 
 
-def test_instance_limit(ctx):
+def test_many_instances(ctx, oracle):
+    """A few thousand instances of two small meshes (a lattice with jitter, some
+    exactly coincident so that ties in t across instances occur): hits and a
+    small render equal the oracle's brute force over (t, instance, primitive)."""
+    rng = np.random.default_rng(5)
     box = scenes.cornell_box()
-    many = R.Scene([box.meshes[0]], [R.Instance(R.IDENTITY, 0, 0)] * 1025, None)
-    with pytest.raises(R.PtcError, match="too many instances"):
-        R.DeviceScene(ctx, many, two_level=True)
+    cube, quad = box.meshes[2], box.meshes[1]
+    instances = []
+    for i in range(3000):
+        cell = np.array([i % 15, (i // 15) % 15, i // 225], np.float32)
+        m = np.eye(3, 4, dtype=np.float32) * np.float32(0.05)
+        m[:, 3] = (cell - 7.0) * 0.13 + rng.uniform(-0.02, 0.02, 3)
+        instances.append(R.Instance(m.astype(np.float32), i % 2, int(rng.integers(0, 4))))
+    for i in range(0, 200, 7):  # exact duplicates with other materials, far apart in index
+        instances.append(R.Instance(instances[i].transform.copy(), instances[i].mesh, (instances[i].kind + 1) % 4))
+    sc = R.Scene([cube, quad], instances, scenes.procedural_sky(32, 16))
+    dev = R.DeviceScene(ctx, sc, two_level=True)
+    orc = oracle.Scene(*sc.oracle_args(), two_level=True)
+    rays = scenes.random_rays(3000, seed=9, radius=2.5)
+    hits = dev.trace(rays)
+    ref, _ = orc.intersect(rays, use_bvh=False)
+    assert np.array_equal(hits["flat"], ref["id"])
+    hit = ref["id"] != oracle.NO_HIT
+    assert hit.mean() > 0.3
+    for k in "tuv":
+        assert np.array_equal(hits[k][hit].view(np.uint32), ref[k][hit].view(np.uint32))
+    w, h = 40, 24
+    cam = R.default_camera(w, h)
+    push = oracle.make_push(cam.as_dict(), frame=2, sample_count=0, samples_per_frame=1)
+    ref_acc, ref_img, _ = orc.render(push, w, h, n_frames=2, max_depth=4, use_bvh=False)
+    for integrator in (R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM):
+        rr = R.RenderResources(ctx, w, h, dev)
+        rr.max_depth = 4
+        rr.integrator = integrator
+        rr.render(cam, frame=2, samples_per_frame=1, n_frames=2)
+        assert np.array_equal(rr.read_accum().view(np.uint32), ref_acc.view(np.uint32)), integrator
+        rr.close()
+    dev.close()
+
+
+def test_tie_between_instances_met_out_of_index_order(ctx, oracle):
+    """Two coplanar quads with power-of-two edges (their t values are bit-equal
+    where they overlap). The instance tree meets the small one (index 1) before
+    the large one (index 0); the hit definition gives the overlap to index 0."""
+    def quad(size):
+        pos = np.array([[-1, -1, 0], [-1 + size, -1, 0], [-1 + size, -1 + size, 0], [-1, -1 + size, 0]], np.float32)
+        nrm = np.tile(np.array([0, 0, 1], np.float32), (4, 1))
+        return R.Mesh(pos, nrm, np.array([[0, 1, 2], [0, 2, 3]], np.uint32))
+    sc = R.Scene([quad(2.0), quad(0.5)], [R.Instance(R.IDENTITY, 0, R.KIND_DIFFUSE), R.Instance(R.IDENTITY, 1, R.KIND_EMISSIVE)],
+                 None)
+    dev = R.DeviceScene(ctx, sc, two_level=True)
+    orc = oracle.Scene(*sc.oracle_args(), two_level=True)
+    rng = np.random.default_rng(1)
+    n = 4000
+    rays = np.zeros((n, 6), np.float32)
+    rays[:, :3] = rng.uniform(-1.5, 1.5, (n, 3)) * [1, 1, 0] + [0, 0, 2]
+    target = np.concatenate([rng.uniform(-1.0, -0.5, (n, 2)), np.zeros((n, 1))], axis=1)  # inside the overlap
+    d = target - rays[:, :3]
+    rays[:, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    hits = dev.trace(rays)
+    ref, _ = orc.intersect(rays, use_bvh=False)
+    assert np.array_equal(hits["flat"], ref["id"])
+    assert (ref["id"] < 2).mean() > 0.9  # the overlap goes to the large quad's triangles (flat 0, 1)
+    w, h = 32, 32
+    cam = R.default_camera(w, h)
+    push = oracle.make_push(cam.as_dict(), frame=0, sample_count=0, samples_per_frame=1)
+    ref_acc, _, _ = orc.render(push, w, h, n_frames=2, max_depth=3, use_bvh=False)
+    for integrator in (R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM):
+        rr = R.RenderResources(ctx, w, h, dev)
+        rr.max_depth = 3
+        rr.integrator = integrator
+        rr.render(cam, frame=0, samples_per_frame=1, n_frames=2)
+        assert np.array_equal(rr.read_accum().view(np.uint32), ref_acc.view(np.uint32)), integrator
+        rr.close()
+    dev.close()
