@@ -67,7 +67,10 @@ typedef struct ptc_camera
 } ptc_camera;
 
 /* One triangle mesh: the three arrays create_render_resources() uploads from
- * aiScene::mMeshes[i] (src/renderer.cpp:1818-1838). Host pointers; copied. */
+ * aiScene::mMeshes[i] (src/renderer.cpp:1818-1838). Host pointers; copied.
+ * Coordinates must be finite and within +-1e9 (the reference's importer
+ * normalises scenes to [-1, 1], src/application.cpp:161); ptc_scene_create
+ * returns PTC_E_INVALID otherwise, and likewise for instance transforms. */
 typedef struct ptc_mesh_desc
 {
     const float *positions;  /* 3 * n_vertices  (aiMesh::mVertices) */

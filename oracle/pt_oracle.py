@@ -296,7 +296,7 @@ class Scene:
             L.pt_scene_set_two_level(self.handle, 1)
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:  # (module globals are gone at interpreter exit)
             lib().pt_scene_destroy(self.handle)
             self.handle = None
 

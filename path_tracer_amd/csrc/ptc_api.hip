@@ -300,6 +300,11 @@ int ptc_synchronize(ptc_context *ctx)
     return PTC_OK;
 }
 
+namespace
+{
+constexpr float kMaxCoordinate = 1e9f; // of a vertex and of a transform entry
+}
+
 int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_meshes,
                      const ptc_instance_desc *instances, uint32_t n_instances,
                      const ptc_envmap_desc *envmap, const ptc_build_options *opts, ptc_scene **out)
@@ -332,6 +337,15 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
                 return PTC_E_INVALID;
             }
         }
+        // box areas are products of two extents: beyond this bound they overflow binary32
+        for (size_t k = 0; k < 3 * (size_t)M.n_vertices; ++k)
+        {
+            if (!(std::fabs(M.positions[k]) <= kMaxCoordinate))
+            {
+                set_error("ptc_scene_create: vertex coordinate not finite or beyond 1e9");
+                return PTC_E_INVALID;
+            }
+        }
         const uint64_t v = (uint64_t)vtx_off[m] + M.n_vertices, t = (uint64_t)tri_off[m] + M.n_triangles;
         if (v > 0x7fffffffu || t > 0x7fffffffu)
         {
@@ -350,6 +364,14 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
         {
             set_error("ptc_scene_create: instance with bad mesh index or material kind");
             return PTC_E_INVALID;
+        }
+        for (int k = 0; k < 12; ++k)
+        {
+            if (!(std::fabs(I.transform[k]) <= kMaxCoordinate))
+            {
+                set_error("ptc_scene_create: instance transform not finite or beyond 1e9");
+                return PTC_E_INVALID;
+            }
         }
         DInstance &D = inst[i];
         std::memset(&D, 0, sizeof D);

@@ -187,5 +187,15 @@ def test_argument_errors(ctx):
     bad = R.Mesh(sc.meshes[0].positions, sc.meshes[0].normals, sc.meshes[0].indices + 10 ** 6)
     with pytest.raises(R.PtcError):
         R.DeviceScene(ctx, R.Scene([bad], [R.Instance(R.IDENTITY, 0, 0)], None))           # vertex index out of range
+    for bad_value in (np.nan, np.inf, 3e38):
+        pos = sc.meshes[0].positions.copy()
+        pos[1, 2] = bad_value
+        with pytest.raises(R.PtcError, match="not finite or beyond"):
+            R.DeviceScene(ctx, R.Scene([R.Mesh(pos, sc.meshes[0].normals, sc.meshes[0].indices)],
+                                       [R.Instance(R.IDENTITY, 0, 0)], None))
+        xf = R.IDENTITY.copy()
+        xf[0, 3] = bad_value
+        with pytest.raises(R.PtcError, match="not finite or beyond"):
+            R.DeviceScene(ctx, R.Scene([sc.meshes[0]], [R.Instance(xf, 0, 0)], None))
     rr.close()
     dev.close()
