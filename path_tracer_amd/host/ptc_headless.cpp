@@ -98,7 +98,7 @@ int main(int argc, char **argv)
         const char *file = nullptr;
         std::string out = "render.png", env;
         std::uint32_t width = 640, height = 480, spp = 64, spf = 1, depth = 32; // src/application.cpp:206-207
-        std::uint32_t preview_every = 0;
+        std::uint32_t preview_every = 0, batch = 64;
         int device = 0;
         bool megakernel = false, two_level = false;
         for (int i = 1; i < argc; ++i)
@@ -122,10 +122,11 @@ int main(int argc, char **argv)
             else if (a == "--megakernel") megakernel = true;
             else if (a == "--two-level") two_level = true;
             else if (a == "--preview-every") preview_every = std::strtoul(next(), nullptr, 10);
+            else if (a == "--batch") batch = std::max(1ul, std::strtoul(next(), nullptr, 10));
             else if (a[0] == '-')
             {
                 std::cerr << "Usage: " << argv[0] << " [<file.obj|.ply>] [--width W] [--height H] [--spp N] [--spf N] "
-                          << "[--depth D] [--megakernel] [--two-level] [--preview-every N] [--env sky.hdr] [--out image.png] [--device N]\n";
+                          << "[--depth D] [--megakernel] [--two-level] [--preview-every N] [--batch N] [--env sky.hdr] [--out image.png] [--device N]\n";
                 return EXIT_FAILURE;
             }
             else file = argv[i];
@@ -175,7 +176,15 @@ int main(int argc, char **argv)
         std::uint32_t next_preview = preview_every;
         while (rr.sample_count < rr.samples_to_render)
         {
-            draw_frame(context, rr, camera);
+            // up to `batch` draw_frame() calls at a time (the same picture as one by
+            // one), stopping at the next preview
+            std::uint32_t calls = batch;
+            if (preview_every != 0 && next_preview > rr.sample_count)
+            {
+                const std::uint32_t spf_now = std::max<std::uint32_t>(rr.samples_per_frame, 1u);
+                calls = std::min(calls, (next_preview - rr.sample_count + spf_now - 1u) / spf_now);
+            }
+            draw_frames(context, rr, camera, std::max<std::uint32_t>(calls, 1u));
             if (preview_every != 0 && rr.sample_count >= next_preview && rr.sample_count < rr.samples_to_render)
             {
                 const std::string msg = write_to_png(context, rr, out.c_str());

@@ -262,6 +262,43 @@ inline void draw_frame(Render_context &context, Render_resources &rr, const Came
     ++context.global_frame_count;
 }
 
+// n consecutive draw_frame() calls with one camera, as one call into the
+// library: the same film and the same counters afterwards (dispatch k uses
+// global_frame_count + k and continues the sample count), but the dispatches
+// that render a full samples_per_frame are in flight together, which is what
+// the wavefront integrator needs to reach its rate. The last, partial dispatch
+// and calls beyond samples_to_render go through draw_frame() itself.
+inline void draw_frames(Render_context &context, Render_resources &rr, const Camera &camera, std::uint32_t n)
+{
+    const std::uint32_t spf = std::max<std::uint32_t>(rr.samples_per_frame, 1u);
+    const std::uint32_t remaining = rr.sample_count < rr.samples_to_render ? rr.samples_to_render - rr.sample_count : 0u;
+    const std::uint32_t n_full = std::min(n, remaining / spf);
+    if (n_full > 1u)
+    {
+        if (rr.sample_count == 0)
+        {
+            detail::check(ptc_film_reset(rr.film), "draw_frames");
+        }
+        ptc_render_params p {};
+        p.global_frame_count = context.global_frame_count;
+        p.samples_per_frame = spf;
+        p.n_frames = n_full;
+        p.max_depth = rr.max_depth;
+        p.integrator = rr.integrator;
+        p.tonemap = rr.tonemap;
+        p.accumulate = PTC_ACCUM_RUNNING_MEAN;
+        detail::check(ptc_film_set_sample_count(rr.film, rr.sample_count), "draw_frames");
+        detail::check(ptc_render(context.handle, rr.scene, rr.film, &camera, &p), "draw_frames");
+        rr.sample_count += n_full * spf;
+        context.global_frame_count += n_full;
+        n -= n_full;
+    }
+    for (; n != 0u; --n)
+    {
+        draw_frame(context, rr, camera);
+    }
+}
+
 // reset_render (src/renderer.cpp:2236-2239)
 inline void reset_render(Render_resources &rr)
 {

@@ -544,6 +544,24 @@ def draw_frame(context: RenderContext, render_resources: RenderResources, camera
     context.global_frame_count = (context.global_frame_count + 1) & 0xFFFFFFFF
 
 
+def draw_frames(context: RenderContext, render_resources: RenderResources, camera: Camera, n: int) -> None:
+    """n consecutive draw_frame() calls with one camera as one call into the
+    library: the same film and counters afterwards, but the dispatches that
+    render a full samples_per_frame are in flight together (what the wavefront
+    integrator needs to reach its rate). The partial last dispatch and calls
+    beyond samples_to_render go through draw_frame()."""
+    rr = render_resources
+    spf = max(rr.samples_per_frame, 1)
+    remaining = max(rr.samples_to_render - rr.sample_count, 0)
+    n_full = min(n, remaining // spf)
+    if n_full > 1:
+        rr.render(camera, context.global_frame_count, spf, n_frames=n_full)
+        context.global_frame_count = (context.global_frame_count + n_full) & 0xFFFFFFFF
+        n -= n_full
+    for _ in range(n):
+        draw_frame(context, rr, camera)
+
+
 def reset_render(render_resources: RenderResources) -> None:
     """reset_render() (src/renderer.cpp:2236-2239)."""
     _check(lib().ptc_film_reset(render_resources.film))

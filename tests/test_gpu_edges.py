@@ -199,3 +199,31 @@ def test_argument_errors(ctx):
             R.DeviceScene(ctx, R.Scene([sc.meshes[0]], [R.Instance(xf, 0, 0)], None))
     rr.close()
     dev.close()
+
+
+def test_draw_frames_equals_consecutive_draw_frame_calls(ctx):
+    """draw_frames(n) = n draw_frame() calls: same film, same counters, including
+    a partial last dispatch and calls beyond samples_to_render."""
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(ctx, sc)
+    w, h = 48, 32
+    cam = R.default_camera(w, h)
+    films = []
+    for batched in (False, True):
+        rr = R.RenderResources(ctx, w, h, dev)
+        rr.max_depth = 6
+        rr.samples_to_render, rr.samples_per_frame = 23, 3   # 7 full dispatches, one of 2 samples, then idle calls
+        ctx.global_frame_count = 40
+        R.reset_render(rr)
+        if batched:
+            R.draw_frames(ctx, rr, cam, 5)
+            R.draw_frames(ctx, rr, cam, 6)
+        else:
+            for _ in range(11):
+                R.draw_frame(ctx, rr, cam)
+        assert rr.sample_count == 23 and ctx.global_frame_count == 51
+        films.append((rr.read_accum(), rr.read_rgba8()))
+        rr.close()
+    assert np.array_equal(_bits(films[0][0]), _bits(films[1][0]))
+    assert np.array_equal(films[0][1], films[1][1])
+    dev.close()

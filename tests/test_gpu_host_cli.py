@@ -41,6 +41,9 @@ def test_progressive_preview_does_not_change_the_picture(tmp_path):
                   "--out", b)
     assert log.count("preview at") == 3 and "preview at 6 samples" in log  # after 2, 4 and 6 of the 8 samples
     assert np.array_equal(np.asarray(Image.open(a)), np.asarray(Image.open(b)))
+    c = str(tmp_path / "one_by_one.png")
+    run_cli("--width", "64", "--height", "48", "--spp", "8", "--spf", "2", "--depth", "4", "--batch", "1", "--out", c)
+    assert np.array_equal(np.asarray(Image.open(a)), np.asarray(Image.open(c)))  # batched calls = single calls
 
 
 def test_obj_file_as_the_reference_scene(tmp_path, ctx):
