@@ -215,12 +215,16 @@ PTC_DEV Payload material_scatter(uint32_t kind, vec3 dir, vec3 pos, vec3 nrm, ui
 {
     vec3 origin, out_dir, color, emissivity;
     float attenuation = 1.0f;
-    if (kind == 0u)
+    // (diffuse.rchit and emissive.rchit differ in two constants only: one branch
+    // for both, so that a wave with lanes of either kind samples the sphere once)
+    if (kind == 0u || kind == 2u)
     {
         origin = offset_position_along_normal(pos, nrm);
         out_dir = reflect_diffuse(nrm, rng);
-        color = v3((nrm.x + 1.0f) * 0.5f, (nrm.y + 1.0f) * 0.5f, (nrm.z + 1.0f) * 0.5f);
-        emissivity = v3(0.0f, 0.0f, 0.0f);
+        const float e = kind == 2u ? 5.0f : 0.0f;
+        color = kind == 2u ? v3(0.75f, 0.75f, 0.75f)
+                           : v3((nrm.x + 1.0f) * 0.5f, (nrm.y + 1.0f) * 0.5f, (nrm.z + 1.0f) * 0.5f);
+        emissivity = v3(e, e, e);
     }
     else if (kind == 1u)
     {
@@ -228,13 +232,6 @@ PTC_DEV Payload material_scatter(uint32_t kind, vec3 dir, vec3 pos, vec3 nrm, ui
         out_dir = reflect(dir, nrm);
         color = v3(0.75f, 0.75f, 0.75f);
         emissivity = v3(0.0f, 0.0f, 0.0f);
-    }
-    else if (kind == 2u)
-    {
-        origin = offset_position_along_normal(pos, nrm);
-        out_dir = reflect_diffuse(nrm, rng);
-        color = v3(0.75f, 0.75f, 0.75f);
-        emissivity = v3(5.0f, 5.0f, 5.0f);
     }
     else
     {
