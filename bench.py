@@ -147,7 +147,9 @@ def main():
     rr.integrator = R.INTEGRATOR_WAVEFRONT if args.integrator == "wavefront" else R.INTEGRATOR_MEGAKERNEL
     rr.wavefront_bounces = args.wavefront_bounces
     # workspace for a whole step in flight: 256 spp at 1080p are 2^29 paths, 85 GB of the 288 GB
-    rr.max_paths_in_flight = min(args.max_paths or args.spp_per_step * W * H, 2 ** 32 - 1)
+    # (bounded by half of the free device memory at about 170 B per path: larger steps run in several batches)
+    fits = int(torch.cuda.mem_get_info(local_rank)[0] * 0.5 / 170)
+    rr.max_paths_in_flight = min(args.max_paths or args.spp_per_step * W * H, fits, 2 ** 32 - 1)
     info = rr.scene.info
     spp = args.spp_per_step
 
