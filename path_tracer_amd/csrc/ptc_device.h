@@ -712,7 +712,9 @@ PTC_DEV void node_eval(const uint4 w0, const uint4 w1, const uint4 w2, const uin
     tg.y = hitmask & ~kNodeBits;
 }
 
-// Loads one wide node and tests it.
+// Loads one wide node and tests it. kTryUniform = false skips the check for a
+// wave-uniform node (kernels whose waves hold unrelated rays almost never pass it).
+template <bool kTryUniform = true>
 PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t node_idx, uint2 &ng,
                        uint2 &tg)
 {
@@ -721,7 +723,7 @@ PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t 
     // cache instead of 64 times through the vector memory path; if the lanes also
     // share the ray octant, the per-node part of the test runs on the scalar unit.
     const uint32_t first_idx = __builtin_amdgcn_readfirstlane(node_idx);
-    if (__builtin_amdgcn_ballot_w64(node_idx != first_idx) == 0ull)
+    if (kTryUniform && __builtin_amdgcn_ballot_w64(node_idx != first_idx) == 0ull)
     {
         // constant address space + wave-uniform address = scalar (SMEM) loads
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -564,7 +564,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             {
                 stack_push<kDrainLds>(lds, kBlock, spill, sp, tg); // triangles found earlier and not tested yet
             }
-            node_test(S, R, best.t, node_idx, ng, tg);
+            node_test<kCamera>(S, R, best.t, node_idx, ng, tg);
         }
         // ---- at most one triangle test per lane and iteration, so that lanes with
         // many pending triangles do not hold the wave
