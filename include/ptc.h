@@ -127,6 +127,12 @@ typedef struct ptc_scene_info
     float build_ms;        /* device time of the BVH build */
     float sah_cost;        /* SAH cost of the wide tree (Ct = Cn = 1) */
     uint64_t device_bytes; /* HBM held by the scene */
+    /* 48-byte triangle records stored beside the nodes: n_triangles for a
+     * flattened scene; for a two_level scene the sum over the meshes (a mesh
+     * that several instances share is stored once, one no instance uses is
+     * stored all the same). This is the count ptc_scene_read_bvh() copies. */
+    uint32_t n_bvh_triangles;
+    uint32_t reserved;
 } ptc_scene_info;
 
 /* 80-byte wide-BVH node and 48-byte triangle as they lie in HBM; returned by
@@ -235,7 +241,10 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes,
                      const ptc_build_options *opts, ptc_scene **out);
 void ptc_scene_destroy(ptc_scene *scene);
 int ptc_scene_get_info(const ptc_scene *scene, ptc_scene_info *out);
-/* Copy the device BVH to host buffers (sizes from ptc_scene_get_info). */
+/* Copy the device BVH to host buffers: n_nodes and n_triangles must equal
+ * ptc_scene_info::n_nodes and ::n_bvh_triangles. In a two_level scene the
+ * arrays hold one tree per mesh, back to back, in object space; a triangle
+ * record's instance word is then 0 and its flat word the primitive index. */
 int ptc_scene_read_bvh(const ptc_scene *scene, ptc_bvh8_node *nodes,
                        size_t n_nodes, ptc_bvh_triangle *triangles,
                        size_t n_triangles);

@@ -1686,6 +1686,48 @@ void pt_render(const pt_scene *S, const pt_push_constants *push,
     }
 }
 
+/* The same dispatches for chosen pixels only: pixel_indices[k] = py * width + px
+ * of a width x height frame; accum / rgba8 hold n entries in that order. A
+ * raygen invocation depends on nothing but its own pixel, so this is exactly
+ * what pt_render() would leave in those pixels. */
+void pt_render_pixels(const pt_scene *S, const pt_push_constants *push,
+                      const pt_render_params *rp, const uint32_t *pixel_indices,
+                      size_t n, float *accum, uint8_t *rgba8, pt_stats *stats)
+{
+    pt_stats total;
+    memset(&total, 0, sizeof total);
+#pragma omp parallel
+    {
+        pt_stats local;
+        memset(&local, 0, sizeof local);
+#pragma omp for schedule(dynamic, 16)
+        for (long long k = 0; k < (long long)n; ++k)
+        {
+            const uint32_t px = pixel_indices[k] % rp->width;
+            const uint32_t py = pixel_indices[k] / rp->width;
+            pt_push_constants pc = *push;
+            for (uint32_t f = 0; f < rp->n_frames; ++f)
+            {
+                raygen(S, &pc, rp, px, py, accum + 4 * k,
+                       rgba8 ? rgba8 + 4 * k : NULL, &local);
+                pc.global_frame_count += 1u;
+                pc.sample_count += pc.samples_per_frame;
+            }
+        }
+#pragma omp critical
+        {
+            total.rays += local.rays;
+            total.paths += local.paths;
+            total.nodes_visited += local.nodes_visited;
+            total.tris_tested += local.tris_tested;
+        }
+    }
+    if (stats)
+    {
+        *stats = total;
+    }
+}
+
 void pt_primary_hits(const pt_scene *S, const pt_push_constants *push,
                      const pt_render_params *rp, uint32_t *ids)
 {

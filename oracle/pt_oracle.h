@@ -179,6 +179,13 @@ void pt_render(const pt_scene *scene, const pt_push_constants *push,
                const pt_render_params *params, float *accum, uint8_t *rgba8,
                pt_stats *stats);
 
+/* The same for n chosen pixels (pixel_indices[k] = py * width + px); accum and
+ * rgba8 hold one entry per chosen pixel, in that order. */
+void pt_render_pixels(const pt_scene *scene, const pt_push_constants *push,
+                      const pt_render_params *params,
+                      const uint32_t *pixel_indices, size_t n, float *accum,
+                      uint8_t *rgba8, pt_stats *stats);
+
 /* flattened triangle index of the first hit of the first sample of every
  * pixel for one dispatch (PT_NO_HIT = sky) */
 void pt_primary_hits(const pt_scene *scene, const pt_push_constants *push,

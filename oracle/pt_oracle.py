@@ -129,6 +129,8 @@ def lib():
         L.pt_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]
         L.pt_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pt_render_pixels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
         L.pt_math_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t]
         L.pt_camera_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -340,6 +342,20 @@ class Scene:
         st = Stats()
         lib().pt_render(self.handle, C.byref(push), C.byref(rp), _ptr(accum),
                         _ptr(rgba8) if want_rgba8 else None, C.byref(st))
+        return accum, rgba8, st
+
+    def render_pixels(self, push: PushConstants, width, height, pixel_indices, n_frames=1, max_depth=32,
+                      tmax=10000.0, accumulate_sum=False, use_bvh=True, tonemap=TONEMAP_PBR_NEUTRAL):
+        """The film pt_render() would leave in the chosen pixels (index = py * width + px)
+        of a fresh width x height film: (accum f32[n, 4], rgba8 u8[n, 4], stats)."""
+        rp = RenderParams(width, height, max_depth, tmax, n_frames, int(accumulate_sum), int(use_bvh), 0,
+                          int(tonemap))
+        idx = np.ascontiguousarray(pixel_indices, dtype=np.uint32).ravel()
+        accum = np.zeros((idx.size, 4), np.float32)
+        rgba8 = np.zeros((idx.size, 4), np.uint8)
+        st = Stats()
+        lib().pt_render_pixels(self.handle, C.byref(push), C.byref(rp), _ptr(idx), idx.size, _ptr(accum),
+                               _ptr(rgba8), C.byref(st))
         return accum, rgba8, st
 
     def primary_hits(self, push: PushConstants, width, height, tmax=10000.0,

@@ -3,6 +3,7 @@
 #include "ptc_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -22,13 +23,18 @@ namespace
 
 // Inverse of a 3x4 affine matrix: cofactor formula in double, rounded once to
 // float. Stands in for the driver's gl_WorldToObjectEXT.
-void inverse_affine(const float m[12], float out[12])
+// Returns false for a singular (or non-finite) linear part.
+bool inverse_affine(const float m[12], float out[12])
 {
     const double a = m[0], b = m[1], c = m[2], tx = m[3];
     const double d = m[4], e = m[5], f = m[6], ty = m[7];
     const double g = m[8], h = m[9], i = m[10], tz = m[11];
     const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
     const double r = 1.0 / det;
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(r))
+    {
+        return false;
+    }
     const double i00 = (e * i - f * h) * r, i01 = (c * h - b * i) * r, i02 = (b * f - c * e) * r;
     const double i10 = (f * g - d * i) * r, i11 = (a * i - c * g) * r, i12 = (c * d - a * f) * r;
     const double i20 = (d * h - e * g) * r, i21 = (b * g - a * h) * r, i22 = (a * e - b * d) * r;
@@ -44,6 +50,14 @@ void inverse_affine(const float m[12], float out[12])
     out[9] = (float)i21;
     out[10] = (float)i22;
     out[11] = (float)(-(i20 * tx + i21 * ty + i22 * tz));
+    for (int k = 0; k < 12; ++k)
+    {
+        if (!std::isfinite(out[k]))
+        {
+            return false;
+        }
+    }
+    return true;
 }
 
 vec3 to_v3(const ptc_vec3 &v)
@@ -221,16 +235,41 @@ int ptc_context_create(int device_ordinal, ptc_context **out)
         return PTC_E_NOMEM;
     }
     ctx->device = device_ordinal;
-    hipDeviceProp_t prop;
-    PTC_HIP_CHECK(hipGetDeviceProperties(&prop, device_ordinal));
-    ctx->n_cus = prop.multiProcessorCount;
-    PTC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    ctx->own_stream = true;
-    PTC_HIP_CHECK(hipMalloc(&ctx->d_stats, sizeof(DeviceStats)));
-    PTC_HIP_CHECK(hipMemsetAsync(ctx->d_stats, 0, sizeof(DeviceStats), ctx->stream));
-    PTC_HIP_CHECK(hipEventCreate(&ctx->ev_start));
-    PTC_HIP_CHECK(hipEventCreate(&ctx->ev_stop));
-    PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // every later failure releases what was created so far
+    auto attempt = [&]() -> int {
+        hipDeviceProp_t prop;
+        PTC_HIP_CHECK(hipGetDeviceProperties(&prop, device_ordinal));
+        ctx->n_cus = prop.multiProcessorCount;
+        PTC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+        PTC_HIP_CHECK(hipMalloc(&ctx->d_stats, sizeof(DeviceStats)));
+        PTC_HIP_CHECK(hipMemsetAsync(ctx->d_stats, 0, sizeof(DeviceStats), ctx->stream));
+        PTC_HIP_CHECK(hipEventCreate(&ctx->ev_start));
+        PTC_HIP_CHECK(hipEventCreate(&ctx->ev_stop));
+        PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return PTC_OK;
+    };
+    const int rc = attempt();
+    if (rc != PTC_OK)
+    {
+        const std::string msg = g_error; // the teardown below may overwrite it
+        if (ctx->ev_start)
+        {
+            (void)hipEventDestroy(ctx->ev_start);
+        }
+        if (ctx->ev_stop)
+        {
+            (void)hipEventDestroy(ctx->ev_stop);
+        }
+        (void)hipFree(ctx->d_stats);
+        if (ctx->own_stream)
+        {
+            (void)hipStreamDestroy(ctx->stream);
+        }
+        delete ctx;
+        set_error(msg);
+        return rc;
+    }
     *out = ctx;
     return PTC_OK;
 }
@@ -376,7 +415,12 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
         DInstance &D = inst[i];
         std::memset(&D, 0, sizeof D);
         std::memcpy(D.o2w, I.transform, sizeof D.o2w);
-        inverse_affine(D.o2w, D.w2o);
+        if (!inverse_affine(D.o2w, D.w2o))
+        {
+            // a zero-scale axis would send rays and normals through an inverse full of inf / NaN
+            set_error("ptc_scene_create: instance transform is singular");
+            return PTC_E_INVALID;
+        }
         D.kind = I.kind;
         D.vtx_offset = vtx_off[I.mesh];
         D.tri_offset = tri_off[I.mesh];
@@ -494,6 +538,7 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
     {
         return fail(rc);
     }
+    S->info.n_bvh_triangles = (uint32_t)(S->d_inst_box ? nt : total);
     S->info.device_bytes = (uint64_t)S->info.n_nodes * 80 + (uint64_t)(S->d_inst_box ? nt : total) * 48 + nv * 24 +
                            nt * 12 + (S->d_inst_box ? n_instances * 32 : 0) +
                            n_instances * sizeof(DInstance) +
@@ -540,9 +585,9 @@ int ptc_scene_read_bvh(const ptc_scene *scene, ptc_bvh8_node *nodes, size_t n_no
         set_error("ptc_scene_read_bvh: NULL argument");
         return PTC_E_INVALID;
     }
-    if (n_nodes != scene->info.n_nodes || n_triangles != scene->info.n_triangles)
+    if (n_nodes != scene->info.n_nodes || n_triangles != scene->info.n_bvh_triangles)
     {
-        set_error("ptc_scene_read_bvh: buffer sizes do not match ptc_scene_get_info");
+        set_error("ptc_scene_read_bvh: buffer sizes do not match n_nodes / n_bvh_triangles of ptc_scene_get_info");
         return PTC_E_INVALID;
     }
     if (use_device(scene->ctx) != PTC_OK)

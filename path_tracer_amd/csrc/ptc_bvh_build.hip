@@ -909,9 +909,25 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
     PTC_HIP_CHECK(pool.alloc(&d_cost, 1));
     PTC_HIP_CHECK(hipMemsetAsync(d_cost, 0, sizeof(double), st));
 
-    hipEvent_t e0, e1;
-    PTC_HIP_CHECK(hipEventCreate(&e0));
-    PTC_HIP_CHECK(hipEventCreate(&e1));
+    // destroyed on every return path
+    struct EventPair
+    {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair()
+        {
+            if (a)
+            {
+                (void)hipEventDestroy(a);
+            }
+            if (b)
+            {
+                (void)hipEventDestroy(b);
+            }
+        }
+    } ev;
+    PTC_HIP_CHECK(hipEventCreate(&ev.a));
+    PTC_HIP_CHECK(hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     PTC_HIP_CHECK(hipEventRecord(e0, st));
 
     uint32_t n_nodes = 1, depth = 1;
@@ -1082,8 +1098,6 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
     PTC_HIP_CHECK(hipStreamSynchronize(st));
     float ms = 0.0f;
     PTC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
 
     // a traversal may hold two stack entries per level (siblings and postponed triangles)
     if (2u * depth + 2u > (uint32_t)kStackTotal)

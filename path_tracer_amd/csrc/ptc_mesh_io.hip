@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -435,6 +436,22 @@ void parse_ply(const std::vector<char> &data, std::vector<RawMesh> &out)
     for (const PlyElement &e : elements)
     {
         const bool is_vertex = e.name == "vertex", is_face = e.name == "face";
+        if (e.props.empty())
+        {
+            continue; // nothing stored per entry, whatever the header's count says
+        }
+        // An entry takes at least one byte per property (binary: the property's
+        // or its list count's size), so the bytes left bound the count a header
+        // may claim; a larger one is refused before anything is reserved.
+        size_t min_entry = 0;
+        for (const PlyProperty &pr : e.props)
+        {
+            min_entry += format == 0 ? 1u : (size_t)ply_size(pr.is_list ? pr.count_type : pr.type);
+        }
+        if (e.count > (size_t)(c.end - c.p) / min_entry)
+        {
+            throw ParseError {"PLY: element count exceeds the file size"};
+        }
         if (is_face)
         {
             m.face_start.reserve(e.count + 1);
@@ -772,7 +789,7 @@ extern "C" int ptc_mesh_file_open(const char *file_name, const ptc_import_option
                 }
             }
         }
-        auto file = new ptc_mesh_file;
+        std::unique_ptr<ptc_mesh_file> file(new ptc_mesh_file);
         for (const RawMesh &m : raw)
         {
             std::vector<Corner> tri = triangulate(m);
@@ -791,11 +808,10 @@ extern "C" int ptc_mesh_file_open(const char *file_name, const ptc_import_option
         }
         if (file->meshes.empty())
         {
-            delete file;
             ptc::set_error("Scene has no meshes"); // src/application.cpp:200
             return PTC_E_IO;
         }
-        *out = file;
+        *out = file.release();
         return PTC_OK;
     }
     catch (const ParseError &e)
@@ -807,6 +823,12 @@ extern "C" int ptc_mesh_file_open(const char *file_name, const ptc_import_option
     {
         ptc::set_error("ptc_mesh_file_open: out of memory");
         return PTC_E_NOMEM;
+    }
+    catch (const std::exception &e)
+    {
+        // no exception may leave an extern "C" function
+        ptc::set_error(std::string("ptc_mesh_file_open: ") + e.what());
+        return PTC_E_IO;
     }
 }
 

@@ -682,9 +682,21 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     const bool two_level = scene->d.inst_box != nullptr;
     const uint32_t wf_bounces = F0.wavefront_bounces;
     // dispatches per batch: bounded so the workspace stays bounded (by default 2^27 paths, about 21 GB)
-    const uint32_t max_batch = std::max<uint32_t>(
+    uint32_t max_batch = std::max<uint32_t>(
         1u, std::min<uint64_t>(F0.n_frames,
                                F0.max_paths_in_flight / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
+    // Path ids and work-item numbers are 32-bit: a batch, with the film padded
+    // to whole 8x8 tiles (the stream integrator's items), must stay below 2^32.
+    {
+        const uint64_t padded = (uint64_t)((F0.width + 7u) >> 3) * ((F0.height + 7u) >> 3) * 64u;
+        const uint64_t fit = 0xffffffffull / (padded * spf);
+        if (fit == 0u)
+        {
+            set_error("ptc_render: width * height * samples_per_frame exceeds 2^32 paths per dispatch");
+            return PTC_E_LIMIT;
+        }
+        max_batch = (uint32_t)std::min<uint64_t>(max_batch, fit);
+    }
     const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
     const size_t n_counts = (size_t)F0.max_depth + 1 + 8; // live paths per bounce, then the drain's queue heads
     // stream mode keeps live paths in registers: only the radiance array is needed

@@ -95,7 +95,7 @@ class SceneInfo(C.Structure):
     _fields_ = [("n_triangles", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("n_instances", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("build_ms", C.c_float), ("sah_cost", C.c_float),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("n_bvh_triangles", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class RenderParams(C.Structure):
@@ -412,7 +412,7 @@ class DeviceScene:
 
     def read_bvh(self):
         nodes = np.empty((self.info.n_nodes, 80), np.uint8)
-        tris = np.empty((self.info.n_triangles, 48), np.uint8)
+        tris = np.empty((self.info.n_bvh_triangles, 48), np.uint8)
         _check(lib().ptc_scene_read_bvh(self.handle, nodes.ctypes.data, nodes.shape[0],
                                         tris.ctypes.data, tris.shape[0]))
         return nodes, tris

@@ -205,6 +205,51 @@ def ref4_scene(mesh: Mesh, envmap: np.ndarray | None = None) -> Scene:
                  envmap=envmap)
 
 
+def write_hdr(file_name: str, rgb: np.ndarray) -> None:
+    """Writes float32 [H, W, 3+] as a Radiance .hdr file (RGBE, flat scanlines):
+    the file format the reference reads its sky from (src/utility.cpp:75-92)."""
+    rgb = np.asarray(rgb, np.float32)[..., :3]
+    h, w = rgb.shape[:2]
+    m = rgb.max(axis=-1)
+    mant, expo = np.frexp(np.where(m > 1e-32, m, 1.0))  # m = mant * 2^expo, mant in [0.5, 1)
+    scale = np.where(m > 1e-32, mant * 256.0 / np.where(m > 1e-32, m, 1.0), 0.0)
+    out = np.zeros((h, w, 4), np.uint8)
+    out[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    out[..., 3] = np.where(m > 1e-32, expo + 128, 0).astype(np.uint8)
+    with open(file_name, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        f.write(out.tobytes())
+
+
+def c5_sky_from_hdr(width: int = 2048, height: int = 1024) -> np.ndarray:
+    """The 4K configuration's environment map the way the reference gets its
+    own: from a Radiance .hdr file on disk through the library's decoder
+    (read_hdr_image, src/utility.cpp:75-92). The file is the procedural sky,
+    written to a temporary directory first; RGBE keeps 8 bits of mantissa, so
+    the array returned is the quantised sky, [H, W, 4] float32."""
+    import os
+    import tempfile
+    from .renderer import read_hdr_image
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "sky.hdr")
+        write_hdr(path, procedural_sky(width, height))
+        return read_hdr_image(path)
+
+
+def dragon_in_cornell(envmap: np.ndarray | None = None, nu: int = 929, nv: int = 469) -> Scene:
+    """Dragon + Cornell box under an environment map: the box's five walls and
+    its light, with the dragon stand-in (specular, 2 * nu * nv triangles) in the
+    place of the two blocks. The box opens towards the camera, so mirror
+    reflections leave through the opening and end on the sky."""
+    box = cornell_box()
+    s = 0.7
+    xf = np.array([[s, 0, 0, 0.0], [0, s, 0, -0.25], [0, 0, s, 0.1]], np.float32)
+    return Scene(meshes=[box.meshes[0], box.meshes[1], knot_mesh(nu, nv)],
+                 instances=[Instance(IDENTITY, 0, KIND_DIFFUSE), Instance(IDENTITY, 1, KIND_EMISSIVE),
+                            Instance(xf, 2, KIND_SPECULAR)],
+                 envmap=envmap)
+
+
 def random_rays(n: int, seed: int = 1, radius: float = 3.0, target_radius: float = 1.0) -> np.ndarray:
     """Incoherent rays: origins on a sphere, aimed at random points near the
     origin; float32 [n, 6]."""
@@ -218,5 +263,5 @@ def random_rays(n: int, seed: int = 1, radius: float = 3.0, target_radius: float
 
 
 __all__ = ["cornell_box", "knot_mesh", "torus_mesh", "procedural_sky", "dragon_scene",
-           "ref4_scene", "random_rays", "KIND_DIFFUSE", "KIND_SPECULAR", "KIND_EMISSIVE",
+           "dragon_in_cornell", "c5_sky_from_hdr", "write_hdr", "ref4_scene", "random_rays", "KIND_DIFFUSE", "KIND_SPECULAR", "KIND_EMISSIVE",
            "KIND_DIELECTRIC"]

@@ -140,6 +140,23 @@ def main():
                                   use_bvh=False)
     np.savez_compressed(os.path.join(HERE, "ref4_32x32_4spp.npz"), accum_bits=acc2.view(np.uint32), rgba8=img2,
                         rays=np.uint64(st2.rays))
+    # (ix) the 4K configuration's scene in small: object in the Cornell box under a sky that went through a
+    # Radiance file. The library's decoder produced the sky; the numpy restatement must decode the same file alike.
+    import tempfile
+    from oracle import hdr_image as H
+    sky = scenes.c5_sky_from_hdr(64, 32)
+    with tempfile.TemporaryDirectory() as d:
+        scenes.write_hdr(os.path.join(d, "sky.hdr"), scenes.procedural_sky(64, 32))
+        restated = H.decode(open(os.path.join(d, "sky.hdr"), "rb").read())
+    assert np.array_equal(sky.view(np.uint32), np.ascontiguousarray(restated, np.float32).view(np.uint32))
+    sc5 = scenes.dragon_in_cornell(sky, nu=64, nv=16)
+    orc5 = O.Scene(*sc5.oracle_args())
+    cam5 = R.default_camera(64, 36)
+    push5 = O.make_push(cam5.as_dict(), frame=1)
+    acc5, img5, st5 = orc5.render(push5, 64, 36, n_frames=4, use_bvh=False)
+    ids5 = orc5.primary_hits(push5, 64, 36, use_bvh=False)
+    np.savez_compressed(os.path.join(HERE, "c5_64x36_4spp.npz"), accum_bits=acc5.view(np.uint32), rgba8=img5,
+                        rays=np.uint64(st5.rays), primary_ids=ids5)
     print("wrote npz fixtures")
 
 

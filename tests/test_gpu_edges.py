@@ -197,6 +197,31 @@ def test_argument_errors(ctx):
         xf[0, 3] = bad_value
         with pytest.raises(R.PtcError, match="not finite or beyond"):
             R.DeviceScene(ctx, R.Scene([sc.meshes[0]], [R.Instance(xf, 0, 0)], None))
+    # a singular transform (zero scale on one axis) has no inverse to take rays to object space with
+    flat_axis = R.IDENTITY.copy()
+    flat_axis[1, 1] = 0.0
+    for two_level in (False, True):
+        with pytest.raises(R.PtcError, match="singular"):
+            R.DeviceScene(ctx, R.Scene([sc.meshes[0]], [R.Instance(flat_axis, 0, 0)], None), two_level=two_level)
+    rr.close()
+    dev.close()
+
+
+def test_path_ids_beyond_32_bits_are_refused(ctx):
+    """Path ids are 32-bit: a dispatch of an 8K film with 130 samples per frame
+    has more paths than that. The queue-based integrators refuse it (before
+    allocating anything); the megakernel, which numbers nothing, is not asked
+    to render it here (it would take minutes)."""
+    sc = scenes.cornell_box()
+    dev = R.DeviceScene(ctx, sc)
+    w, h = 7680, 4320
+    rr = R.RenderResources(ctx, w, h, dev)
+    cam = R.default_camera(w, h)
+    for integrator in (R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM, R.INTEGRATOR_AUTO):
+        rr.integrator = integrator
+        with pytest.raises(R.PtcError, match="exceeds 2\\^32 paths"):
+            rr.render(cam, frame=0, samples_per_frame=130)
+        assert rr.sample_count == 0
     rr.close()
     dev.close()
 

@@ -122,4 +122,79 @@ def test_ten_million_triangles_build_and_trace(ctx, oracle):
     assert np.array_equal(ref["id"], h1["flat"][:20000])
     print(f"10M build {dev.info.build_ms:.1f} ms, nodes {dev.info.n_nodes}, depth {dev.info.bvh_depth}, "
           f"SAH {dev.info.sah_cost:.1f}, nodes/ray {st.nodes_visited / len(rays):.1f}")
+    # The configuration as it is stated: diffuse, depth 8, rendered at 1920x1080. The three integrators leave the
+    # same film bit for bit, and a sample of its pixels equals the oracle's render of those pixels (the oracle
+    # walks its own tree over the same world-space triangles; both equal the brute-force definition).
+    w, h = 1920, 1080
+    cam = R.default_camera(w, h)
+    films = {}
+    for name, integ in (("mega", R.INTEGRATOR_MEGAKERNEL), ("wave", R.INTEGRATOR_WAVEFRONT),
+                        ("stream", R.INTEGRATOR_STREAM)):
+        rr = R.RenderResources(ctx, w, h, dev)
+        rr.integrator, rr.max_depth = integ, 8
+        ctx.reset_stats()
+        rr.render(cam, frame=4, n_frames=2)
+        films[name] = (rr.read_accum(), rr.read_rgba8(), ctx.stats().rays)
+        rr.close()
+    for name in ("wave", "stream"):
+        assert np.array_equal(films["mega"][0].view(np.uint32), films[name][0].view(np.uint32)), name
+        assert np.array_equal(films["mega"][1], films[name][1]), name
+        assert films["mega"][2] == films[name][2], name
+    assert films["mega"][2] > 2.5 * w * h  # diffuse bounces: well over one ray per path
+    orc = oracle.Scene(*sc.oracle_args())
+    rng = np.random.default_rng(5)
+    pix = np.unique(np.concatenate([rng.integers(0, w * h, 6000), (h // 2) * w + np.arange(w)])).astype(np.uint32)
+    ref_acc, ref_img, _ = orc.render_pixels(oracle.make_push(cam.as_dict(), frame=4), w, h, pix, n_frames=2, max_depth=8)
+    got_acc = films["wave"][0].reshape(-1, 4)[pix]
+    assert np.array_equal(got_acc.view(np.uint32), ref_acc.view(np.uint32)), \
+        f"{np.count_nonzero((got_acc.view(np.uint32) != ref_acc.view(np.uint32)).any(axis=1))} of {pix.size} pixels differ"
+    assert np.array_equal(films["wave"][1].reshape(-1, 4)[pix], ref_img)
+    ids = dev.primary_hits(cam, w, h, frame=4)
+    ref_ids = orc.primary_hits(oracle.make_push(cam.as_dict(), frame=4), w, h, use_bvh=True)
+    assert np.array_equal(ids, ref_ids)
+    dev.close()
+
+
+def test_dragon_in_cornell_box_under_hdr_sky_at_4k(ctx, oracle):
+    """Dragon + Cornell box + environment map at 3840x2160, megakernel against
+    wavefront: the two films are identical, every primary-ray triangle id of
+    the full frame equals the oracle's, a sample of the film's pixels equals
+    the oracle's render of them, and so does a whole 64x36 film of the scene."""
+    sc = scenes.dragon_in_cornell(scenes.c5_sky_from_hdr(1024, 512))
+    dev = R.DeviceScene(ctx, sc)
+    orc = oracle.Scene(*sc.oracle_args())
+    assert dev.info.n_triangles == 871402 + 12
+    w, h = 3840, 2160
+    cam = R.default_camera(w, h)
+    films = {}
+    for name, integ in (("mega", R.INTEGRATOR_MEGAKERNEL), ("wave", R.INTEGRATOR_WAVEFRONT)):
+        rr = R.RenderResources(ctx, w, h, dev)
+        rr.integrator = integ
+        ctx.reset_stats()
+        rr.render(cam, frame=9, n_frames=2)
+        films[name] = (rr.read_accum(), rr.read_rgba8(), ctx.stats().rays)
+        rr.close()
+    assert np.array_equal(films["mega"][0].view(np.uint32), films["wave"][0].view(np.uint32))
+    assert np.array_equal(films["mega"][1], films["wave"][1])
+    assert films["mega"][2] == films["wave"][2] > 2 * 2 * w * h  # closed box: paths bounce
+    push = oracle.make_push(cam.as_dict(), frame=9)
+    ids = dev.primary_hits(cam, w, h, frame=9)
+    ref_ids = orc.primary_hits(push, w, h, use_bvh=True)
+    assert np.array_equal(ids, ref_ids), f"{np.count_nonzero(ids != ref_ids)} primary ids differ"
+    assert (ids >= 12).mean() > 0.03 and (ids != oracle.NO_HIT).mean() > 0.4  # the object and the box are in view
+    rng = np.random.default_rng(6)
+    on_object = np.flatnonzero(ids.ravel() >= 12)
+    pix = np.unique(np.concatenate([rng.integers(0, w * h, 3000), rng.choice(on_object, 3000)])).astype(np.uint32)
+    ref_acc, ref_img, _ = orc.render_pixels(push, w, h, pix, n_frames=2)
+    got = films["wave"][0].reshape(-1, 4)[pix]
+    assert np.array_equal(got.view(np.uint32), ref_acc.view(np.uint32))
+    assert np.array_equal(films["wave"][1].reshape(-1, 4)[pix], ref_img)
+    # the same scene and camera on a 64x36 film, whole film against the oracle
+    cam_s = R.default_camera(64, 36)
+    rr = R.RenderResources(ctx, 64, 36, dev)
+    rr.render(cam_s, frame=0, n_frames=8)
+    ref_acc, ref_img, _ = orc.render(oracle.make_push(cam_s.as_dict(), frame=0), 64, 36, n_frames=8)
+    assert np.array_equal(rr.read_accum().view(np.uint32), ref_acc.view(np.uint32))
+    assert np.array_equal(rr.read_rgba8(), ref_img)
+    rr.close()
     dev.close()

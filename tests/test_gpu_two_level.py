@@ -50,6 +50,58 @@ def test_hits_match_the_two_level_definition(pair, oracle):
     assert dev.info.n_triangles == sc.n_triangles  # ids stay flattened ids
 
 
+def test_read_bvh_returns_one_tree_per_mesh(pair, oracle):
+    """ptc_scene_read_bvh on a two-level scene copies the stored records: one
+    tree per mesh (a mesh shared by several instances once), n_bvh_triangles of
+    them, not the flattened count. Every mesh's tree validates on its own
+    against that mesh's object-space triangles."""
+    name, sc, dev, orc = pair
+    stored = sum(m.indices.shape[0] for m in sc.meshes)
+    assert dev.info.n_bvh_triangles == stored
+    if name == "ref4":
+        assert dev.info.n_triangles == 4 * stored
+    nodes, tris = dev.read_bvh()
+    assert nodes.shape == (dev.info.n_nodes, 80) and tris.shape == (stored, 48)
+    words = tris.view(np.uint32).reshape(-1, 12)
+    # records of mesh m: primitive = 0 .. n_m - 1, each exactly once, in the mesh's slice
+    at = 0
+    for m in sc.meshes:
+        n = m.indices.shape[0]
+        assert np.array_equal(np.sort(words[at:at + n, 7]), np.arange(n, dtype=np.uint32)), name
+        at += n
+    # the first non-empty mesh's tree sits at node 0 and validates against its object-space triangles
+    first = next(m for m in sc.meshes if m.indices.shape[0])
+    n0 = first.indices.shape[0]
+    t0 = 0
+    for m in sc.meshes:
+        if m is first:
+            break
+        t0 += m.indices.shape[0]
+    lone = oracle.Scene([(first.positions, first.normals, first.indices)], [(R.IDENTITY, 0, 0)], None)
+    n_nodes0 = _subtree_nodes(nodes, 0)
+    sub = tris[t0:t0 + n0].copy()
+    sub.view(np.uint32).reshape(-1, 12)[:, 11] = sub.view(np.uint32).reshape(-1, 12)[:, 7]  # flat := primitive
+    sub_nodes = nodes[:n_nodes0].copy()
+    sub_nodes.view(np.uint32).reshape(-1, 20)[:, 5] -= t0  # tri_base back to the mesh's own numbering
+    rc, _ = oracle.bvh8_validate(sub_nodes, sub, lone.world_triangles())
+    assert rc == 0, (name, rc)
+
+
+def _subtree_nodes(nodes, root):
+    """Number of nodes of the tree rooted at `root` (children are stored behind it, breadth first)."""
+    w = nodes.view(np.uint32).reshape(-1, 20)
+    last, todo = root, [root]
+    while todo:
+        i = todo.pop()
+        imask = int(w[i, 3]) >> 24
+        k = bin(imask).count("1")
+        base = int(w[i, 4])
+        for c in range(base, base + k):
+            last = max(last, c)
+            todo.append(c)
+    return last + 1 - root
+
+
 def test_agrees_with_the_flattened_scene_up_to_rounding(pair, ctx):
     name, sc, dev, orc = pair
     flat = R.DeviceScene(ctx, sc)

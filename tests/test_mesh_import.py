@@ -155,6 +155,15 @@ def test_degenerate_faces_polygons_and_groups(tmp_path):
     (b"f 1 2 3\n", "bad.obj", "out of range"),
     (b"solid x\n", "x.stl", "No suitable reader"),
     (b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\n", "cut.ply", "header not terminated"),
+    # a face count no file could hold: refused before anything is reserved (no exception leaves the C ABI)
+    (b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\n"
+     b"element face 99999999999999999999\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n",
+     "huge.ply", "element count exceeds the file size"),
+    (b"ply\nformat binary_little_endian 1.0\nelement vertex 4000000000\nproperty float x\nend_header\n\0\0\0\0",
+     "huge_bin.ply", "element count exceeds the file size"),
+    # an element without properties stores nothing, whatever its count claims
+    (b"ply\nformat ascii 1.0\nelement pad 18446744073709551615\nelement vertex 1\nproperty float x\nend_header\n0\n",
+     "pad.ply", "Scene has no meshes"),
 ])
 def test_import_errors(tmp_path, content, name, reason):
     path = tmp_path / name

@@ -253,6 +253,29 @@ def test_render_golden_images(oracle):
     assert np.array_equal(acc.view(np.uint32), g["accum_bits"]) and np.array_equal(img, g["rgba8"])
 
 
+def test_c5_scene_golden_image(oracle):
+    """Object in the Cornell box under a sky that went through a Radiance file:
+    the numpy decoder and the library's give the same texels, and the oracle
+    (BVH and brute force) renders the committed film from them."""
+    import tempfile
+    from oracle import hdr_image as H
+    g = np.load(os.path.join(GOLD, "c5_64x36_4spp.npz"))
+    sky = scenes.c5_sky_from_hdr(64, 32)
+    with tempfile.TemporaryDirectory() as d:
+        scenes.write_hdr(os.path.join(d, "sky.hdr"), scenes.procedural_sky(64, 32))
+        restated = H.decode(open(os.path.join(d, "sky.hdr"), "rb").read())
+    assert np.array_equal(sky.view(np.uint32), np.ascontiguousarray(restated, np.float32).view(np.uint32))
+    sc = scenes.dragon_in_cornell(sky, nu=64, nv=16)
+    orc = oracle.Scene(*sc.oracle_args())
+    cam = R.default_camera(64, 36)
+    push = oracle.make_push(cam.as_dict(), frame=1)
+    for use_bvh in (False, True):
+        acc, img, st = orc.render(push, 64, 36, n_frames=4, use_bvh=use_bvh)
+        assert np.array_equal(acc.view(np.uint32), g["accum_bits"]) and np.array_equal(img, g["rgba8"])
+        assert st.rays == int(g["rays"])
+        assert np.array_equal(orc.primary_hits(push, 64, 36, use_bvh=use_bvh), g["primary_ids"])
+
+
 def test_running_mean_equals_batched_dispatches(oracle):
     """n_frames dispatches in one call == the same dispatches one call at a
     time feeding the accumulator back (shader.rgen:202-216); alpha stays 1."""
