@@ -101,6 +101,7 @@ def test_device_math_on_the_committed_tone_map_inputs(ctx):
         rr.tonemap = tonemap
         rr.max_depth = 1
         rr.render(R.default_camera(n, 1), frame=0)
+        ctx.synchronize()  # the context's stream is not torch's: the render must be over before torch writes the film
         d_acc.copy_(torch.from_numpy(acc))
         torch.cuda.synchronize()
         rr.resolve(sum_mode=False)
