@@ -273,6 +273,25 @@ int ptc_film_resolve(ptc_film *film, int sum_mode);
 int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
                const ptc_camera *camera, const ptc_render_params *params);
 
+/* ptc_render() for callers that cannot allocate device memory: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc. It has
+ * no counterpart in the reference. Same arguments, same film bit for bit; the
+ * queue-based integrators take their workspace from a 64 MiB array that the
+ * library holds statically on every GPU it is loaded on, instead of the
+ * context's hipMalloc'ed one, and the call creates no events (ptc_render_times
+ * and ptc_phase_times do not see it). It calls no hipMalloc / hipFree and never
+ * synchronises. Limit: one dispatch (width * height * samples_per_frame paths)
+ * must fit the array — 156 bytes per path with the wavefront integrator (the
+ * reference's default 640x480 film at one sample per frame fits), 16 with the
+ * stream integrator (4 M paths); the megakernel uses no workspace. Beyond it:
+ * PTC_E_LIMIT with the sizes in ptc_last_error(), nothing rendered. n_frames
+ * beyond what fits run in several batches, as in ptc_render().
+ * All calls on one GPU share the array (also from different contexts): calls
+ * that overlap in time on one GPU race; calls on one context's stream are
+ * ordered and safe. */
+int ptc_render_static(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
+                      const ptc_camera *camera, const ptc_render_params *params);
+
 /* Flattened triangle index hit by the first sample's camera ray of every
  * pixel for one dispatch (the hit the reference would report through
  * gl_InstanceID / gl_PrimitiveID at bounce 0). ids_out: w*h host uint32. */

@@ -247,7 +247,8 @@ int ptc_context_create(int device_ordinal, ptc_context **out)
         PTC_HIP_CHECK(hipEventCreate(&ctx->ev_start));
         PTC_HIP_CHECK(hipEventCreate(&ctx->ev_stop));
         PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        return PTC_OK;
+        // device address of the static workspace of ptc_render_static on this device
+        return wavefront_static_init(ctx);
     };
     const int rc = attempt();
     if (rc != PTC_OK)
@@ -761,8 +762,15 @@ int ptc_film_resolve(ptc_film *film, int sum_mode)
     return launch_resolve(film->ctx, film, sum_mode);
 }
 
-int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const ptc_camera *camera,
-               const ptc_render_params *params)
+} // extern "C"
+
+namespace
+{
+// ptc_render and ptc_render_static: the same dispatch bookkeeping and kernels;
+// the second takes its workspace from the library's static device array and
+// creates no events, so nothing in it allocates.
+int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const ptc_camera *camera,
+                const ptc_render_params *params, bool static_scratch)
 {
     if (!ctx || !scene || !film || !camera || !params)
     {
@@ -813,18 +821,22 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
     F.wavefront_bounces = params->wavefront_bounces;
     F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : (1u << 27);
     // one event pair per call, kept until ptc_render_times() collects them
+    // (the static variant records none: creating events allocates)
     constexpr size_t kMaxTimed = 256;
-    if (ctx->ev_used == ctx->ev_pool.size() && ctx->ev_pool.size() < kMaxTimed)
+    if (!static_scratch && ctx->ev_used == ctx->ev_pool.size() && ctx->ev_pool.size() < kMaxTimed)
     {
         hipEvent_t a, b;
         PTC_HIP_CHECK(hipEventCreate(&a));
         PTC_HIP_CHECK(hipEventCreate(&b));
         ctx->ev_pool.emplace_back(a, b);
     }
-    const bool timed = ctx->ev_used < ctx->ev_pool.size();
+    const bool timed = !static_scratch && ctx->ev_used < ctx->ev_pool.size();
     hipEvent_t ev0 = timed ? ctx->ev_pool[ctx->ev_used].first : ctx->ev_start;
     hipEvent_t ev1 = timed ? ctx->ev_pool[ctx->ev_used].second : ctx->ev_stop;
-    PTC_HIP_CHECK(hipEventRecord(ev0, ctx->stream));
+    if (!static_scratch)
+    {
+        PTC_HIP_CHECK(hipEventRecord(ev0, ctx->stream));
+    }
     int rc;
     uint32_t integrator = params->integrator;
     if (integrator == PTC_INTEGRATOR_AUTO)
@@ -834,25 +846,45 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const p
         const uint64_t in_flight = std::min<uint64_t>(F.n_frames, std::max<uint64_t>(F.max_paths_in_flight / per_dispatch, 1u));
         integrator = F.samples_per_frame == 1u || in_flight >= 16u ? PTC_INTEGRATOR_WAVEFRONT : PTC_INTEGRATOR_STREAM;
     }
+    ctx->no_events = static_scratch;
     if (integrator != PTC_INTEGRATOR_MEGAKERNEL)
     {
-        rc = launch_render_wavefront(ctx, scene, film, F, integrator == PTC_INTEGRATOR_STREAM);
+        rc = launch_render_wavefront(ctx, scene, film, F, integrator == PTC_INTEGRATOR_STREAM, static_scratch);
     }
     else
     {
         rc = launch_render_mega(ctx, scene, film, F, params->instrument != 0);
     }
+    ctx->no_events = false;
     if (rc != PTC_OK)
     {
         return rc;
     }
-    PTC_HIP_CHECK(hipEventRecord(ev1, ctx->stream));
+    if (!static_scratch)
+    {
+        PTC_HIP_CHECK(hipEventRecord(ev1, ctx->stream));
+    }
     if (timed)
     {
         ++ctx->ev_used;
     }
     film->sample_count += (uint32_t)added;
     return PTC_OK;
+}
+} // namespace
+
+extern "C" {
+
+int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const ptc_camera *camera,
+               const ptc_render_params *params)
+{
+    return render_impl(ctx, scene, film, camera, params, false);
+}
+
+int ptc_render_static(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const ptc_camera *camera,
+                      const ptc_render_params *params)
+{
+    return render_impl(ctx, scene, film, camera, params, true);
 }
 
 int ptc_primary_hits(ptc_context *ctx, const ptc_scene *scene, const ptc_camera *camera,

@@ -59,6 +59,10 @@ struct ptc_context
     // wavefront integrator workspace, grown on demand
     void *wf_buf = nullptr;
     size_t wf_bytes = 0;
+    // the library's static device array on this context's device (ptc_render_static)
+    void *static_scratch = nullptr;
+    size_t static_scratch_bytes = 0;
+    bool no_events = false; // set for the duration of a call that must not create events
 };
 
 struct ptc_scene
@@ -98,6 +102,10 @@ struct PhaseTimer
     hipEvent_t stop = nullptr;
     PhaseTimer(ptc_context *c, uint32_t tag) : ctx(c)
     {
+        if (ctx->no_events)
+        {
+            return;
+        }
         if (ctx->phase_used == ctx->phase_pool.size() && ctx->phase_pool.size() < 1024)
         {
             ptc_context::PhaseEvent e{};
@@ -139,8 +147,13 @@ int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &
 // Render kernels (ptc_render.hip, ptc_wavefront.hip).
 int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &frame,
                        bool count);
+// static_scratch: the workspace is the library's static device array instead of
+// ctx->wf_buf; nothing is allocated, freed or synchronised, and a call whose
+// single dispatch does not fit returns PTC_E_LIMIT.
 int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
-                            const DFrame &frame, bool stream);
+                            const DFrame &frame, bool stream, bool static_scratch);
+// Looks up the device address of the static array on ctx's (current) device.
+int wavefront_static_init(ptc_context *ctx);
 int launch_primary_hits(ptc_context *ctx, const ptc_scene *scene, const DFrame &frame,
                         uint32_t *d_ids);
 int launch_trace(ptc_context *ctx, const ptc_scene *scene, const float *d_rays, size_t n,

@@ -28,6 +28,18 @@
 #include "ptc_internal.h"
 
 #include <algorithm>
+#include <string>
+
+// Workspace of ptc_render_static(): callers that cannot allocate (code under
+// HIP graph capture, serving loops, harnesses that forbid hipMalloc) render
+// into this array instead of a hipMalloc'ed workspace. 64 MiB holds one
+// dispatch of the reference's default 640x480 film (src/application.cpp:206-207)
+// at one sample per frame with the wavefront integrator (156 bytes per path),
+// or 4 M paths with the stream integrator (16 bytes per path). Every GPU the
+// library runs on holds one copy from module load to process end; all calls on
+// a GPU share it, so calls that overlap on one GPU race.
+constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 namespace ptc
 {
@@ -666,7 +678,34 @@ size_t align256(size_t x)
     return (x + 255) & ~(size_t)255;
 }
 
+// Workspace bytes of a batch of max_batch dispatches (the carving order of
+// launch_render_wavefront below).
+size_t workspace_bytes(size_t n_pixels, uint32_t spf, uint32_t max_batch, size_t n_counts, bool stream)
+{
+    const size_t cap = n_pixels * max_batch;
+    const size_t qcap = stream ? 1 : cap;
+    return 2 * (align256(qcap * 16) * 3 + align256(qcap * 8)) + align256(qcap * 16) + align256(qcap * 8) +
+           align256(cap * spf * 16) + align256(n_counts * 4) + align256(qcap * 4);
+}
+
 } // namespace
+
+int wavefront_static_init(ptc_context *ctx)
+{
+    // `scratch` is a host-side stand-in for the device array, not an address a
+    // kernel can use: the device address on the current device comes from here
+    // and is what every later use (kernel arguments, memsets) takes.
+    void *ptr = nullptr;
+    PTC_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (ptr == nullptr)
+    {
+        set_error("hipGetSymbolAddress returned no address for the static workspace");
+        return PTC_E_DEVICE;
+    }
+    ctx->static_scratch = ptr;
+    ctx->static_scratch_bytes = kStaticScratchBytes;
+    return PTC_OK;
+}
 
 // Renders F.n_frames dispatches of F.samples_per_frame samples with ray queues.
 // Dispatches are independent (each re-seeds its RNG), so a batch of them is in
@@ -674,7 +713,7 @@ size_t align256(size_t x)
 // as successive passes, each pass starting from the state the previous sample
 // of the same pixel ended with.
 int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &F0,
-                            bool stream)
+                            bool stream, bool static_scratch)
 {
     hipStream_t st = ctx->stream;
     const uint32_t n_pixels = F0.width * F0.height;
@@ -697,22 +736,49 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
         }
         max_batch = (uint32_t)std::min<uint64_t>(max_batch, fit);
     }
-    const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
     const size_t n_counts = (size_t)F0.max_depth + 1 + 8; // live paths per bounce, then the drain's queue heads
+    char *workspace = nullptr;
+    if (static_scratch)
+    {
+        // as many dispatches per batch as the static array holds; one at least
+        if (ctx->static_scratch == nullptr)
+        {
+            set_error("ptc_render_static: the static workspace was not set up on this device");
+            return PTC_E_DEVICE;
+        }
+        while (max_batch > 1u && workspace_bytes(n_pixels, spf, max_batch, n_counts, stream) > ctx->static_scratch_bytes)
+        {
+            max_batch = max_batch / 2u;
+        }
+        const size_t need = workspace_bytes(n_pixels, spf, max_batch, n_counts, stream);
+        if (need > ctx->static_scratch_bytes)
+        {
+            set_error("ptc_render_static: one dispatch of " + std::to_string(n_pixels) + " pixels x " +
+                      std::to_string(spf) + " samples needs " + std::to_string(need) +
+                      " bytes of workspace, the static array holds " + std::to_string(ctx->static_scratch_bytes) +
+                      " (use ptc_render, a smaller film or fewer samples per frame)");
+            return PTC_E_LIMIT;
+        }
+        workspace = static_cast<char *>(ctx->static_scratch);
+    }
+    const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
     // stream mode keeps live paths in registers: only the radiance array is needed
     const size_t qcap = stream ? 1 : cap;
-    const size_t bytes = 2 * (align256(qcap * 16) * 3 + align256(qcap * 8)) + align256(qcap * 16) + align256(qcap * 8) +
-                         align256(cap * spf * 16) + align256(n_counts * 4) + align256(qcap * 4);
-    if (bytes > ctx->wf_bytes)
+    const size_t bytes = workspace_bytes(n_pixels, spf, max_batch, n_counts, stream);
+    if (!static_scratch)
     {
-        PTC_HIP_CHECK(hipStreamSynchronize(st));
-        (void)hipFree(ctx->wf_buf);
-        ctx->wf_buf = nullptr;
-        ctx->wf_bytes = 0;
-        PTC_HIP_CHECK(hipMalloc(&ctx->wf_buf, bytes));
-        ctx->wf_bytes = bytes;
+        if (bytes > ctx->wf_bytes)
+        {
+            PTC_HIP_CHECK(hipStreamSynchronize(st));
+            (void)hipFree(ctx->wf_buf);
+            ctx->wf_buf = nullptr;
+            ctx->wf_bytes = 0;
+            PTC_HIP_CHECK(hipMalloc(&ctx->wf_buf, bytes));
+            ctx->wf_bytes = bytes;
+        }
+        workspace = static_cast<char *>(ctx->wf_buf);
     }
-    char *p = static_cast<char *>(ctx->wf_buf);
+    char *p = workspace;
     auto take = [&](size_t n) {
         char *r = p;
         p += align256(n);

@@ -120,7 +120,7 @@ EXPORTS = [
     "ptc_scene_create", "ptc_scene_destroy", "ptc_scene_get_info", "ptc_scene_read_bvh",
     "ptc_film_create", "ptc_film_destroy", "ptc_film_reset", "ptc_film_sample_count",
     "ptc_film_set_sample_count", "ptc_film_read_accum", "ptc_film_read_rgba8",
-    "ptc_film_accum_device_ptr", "ptc_film_resolve", "ptc_render", "ptc_primary_hits",
+    "ptc_film_accum_device_ptr", "ptc_film_resolve", "ptc_render", "ptc_render_static", "ptc_primary_hits",
     "ptc_trace_rays", "ptc_trace_rays_device", "ptc_get_stats", "ptc_render_times",
     "ptc_phase_times",
     "ptc_reset_stats",
@@ -162,6 +162,7 @@ def lib():
         L.ptc_film_accum_device_ptr.restype = vp
         L.ptc_film_resolve.argtypes = [vp, C.c_int]
         L.ptc_render.argtypes = [vp, vp, vp, C.POINTER(Camera), C.POINTER(RenderParams)]
+        L.ptc_render_static.argtypes = [vp, vp, vp, C.POINTER(Camera), C.POINTER(RenderParams)]
         L.ptc_primary_hits.argtypes = [vp, vp, C.POINTER(Camera), u32, u32, u32, f32, vp]
         L.ptc_trace_rays.argtypes = [vp, vp, vp, sz, f32, vp, C.POINTER(Stats)]
         L.ptc_trace_rays_device.argtypes = [vp, vp, vp, sz, f32, vp]
@@ -481,7 +482,9 @@ class RenderResources:
         _check(lib().ptc_film_set_sample_count(self.film, v))
 
     def render(self, camera: Camera, frame: int, samples_per_frame: int = 1, n_frames: int = 1,
-               frame_stride: int = 1):
+               frame_stride: int = 1, static: bool = False):
+        """ptc_render, or with static=True ptc_render_static (no allocation; the
+        library's static workspace bounds the paths of one dispatch)."""
         p = RenderParams()
         p.global_frame_count = frame
         p.samples_per_frame = samples_per_frame
@@ -495,8 +498,8 @@ class RenderResources:
         p.wavefront_bounces = self.wavefront_bounces
         p.max_paths_in_flight = self.max_paths_in_flight
         p.tonemap = self.tonemap
-        _check(lib().ptc_render(self.ctx.handle, self.scene.handle, self.film, C.byref(camera),
-                                C.byref(p)))
+        call = lib().ptc_render_static if static else lib().ptc_render
+        _check(call(self.ctx.handle, self.scene.handle, self.film, C.byref(camera), C.byref(p)))
 
     def read_accum(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 4), np.float32)

@@ -1,0 +1,92 @@
+"""ptc_render_static, the render entry point that allocates nothing, against
+ptc_render: the same film bit for bit, on two calls in a row, the second with
+a smaller film (the static workspace keeps the first call's contents), for
+every integrator; calls beyond the workspace's limit are refused."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from path_tracer_amd import renderer as R
+from path_tracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _film(ctx, dev, w, h, integrator, static, frame, spf, n_frames, max_depth=8):
+    cam = R.default_camera(w, h)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.integrator, rr.max_depth = integrator, max_depth
+    ctx.reset_stats()
+    # two calls: a fresh film, then a continuation
+    rr.render(cam, frame=frame, samples_per_frame=spf, n_frames=n_frames, static=static)
+    rr.render(cam, frame=frame + n_frames, samples_per_frame=spf, n_frames=1, static=static)
+    out = (rr.read_accum(), rr.read_rgba8(), ctx.stats().rays, rr.sample_count)
+    rr.close()
+    return out
+
+
+@pytest.mark.parametrize("integrator", [R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM, R.INTEGRATOR_AUTO,
+                                        R.INTEGRATOR_MEGAKERNEL],
+                         ids=["wavefront", "stream", "auto", "megakernel"])
+def test_static_entry_point_equals_ptc_render_on_two_calls_in_a_row(ctx, integrator):
+    sc = scenes.ref4_scene(scenes.knot_mesh(nu=96, nv=24), scenes.procedural_sky(64, 32))
+    dev = R.DeviceScene(ctx, sc)
+    # first the reference's default film (640x480: one dispatch nearly fills the 64 MiB workspace,
+    # so the three dispatches run as three batches), then a smaller, odd-sized one
+    for (w, h, spf, n_frames) in ((640, 480, 1, 3), (123, 77, 2, 5)):
+        if integrator in (R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_AUTO) and w * h * spf * 156 > (64 << 20):
+            continue
+        ref = _film(ctx, dev, w, h, integrator, False, frame=7, spf=spf, n_frames=n_frames)
+        got = _film(ctx, dev, w, h, integrator, True, frame=7, spf=spf, n_frames=n_frames)
+        assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), (w, h)
+        assert np.array_equal(got[1], ref[1]), (w, h)
+        assert got[2:] == ref[2:], (w, h)
+    dev.close()
+
+
+def test_static_entry_point_two_level_scene_and_limits(ctx):
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(ctx, sc, two_level=True)
+    for integrator in (R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM):
+        for (w, h) in ((200, 150), (64, 40)):
+            ref = _film(ctx, dev, w, h, integrator, False, frame=0, spf=1, n_frames=20)
+            got = _film(ctx, dev, w, h, integrator, True, frame=0, spf=1, n_frames=20)
+            assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32))
+            assert np.array_equal(got[1], ref[1]) and got[2:] == ref[2:]
+    # beyond the limit: one 1080p dispatch needs 323 MB with the wavefront integrator
+    w, h = 1920, 1080
+    cam = R.default_camera(w, h)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.integrator = R.INTEGRATOR_WAVEFRONT
+    with pytest.raises(R.PtcError, match="static array holds 67108864"):
+        rr.render(cam, frame=0, static=True)
+    assert rr.sample_count == 0
+    # ... and 33 MB with the stream integrator, which fits; three samples per frame do not
+    rr.integrator = R.INTEGRATOR_STREAM
+    rr.render(cam, frame=0, static=True)
+    static_film = rr.read_accum()
+    R.reset_render(rr)
+    rr.render(cam, frame=0)
+    assert np.array_equal(static_film.view(np.uint32), rr.read_accum().view(np.uint32))
+    R.reset_render(rr)
+    with pytest.raises(R.PtcError, match="static array holds"):
+        rr.render(cam, frame=0, samples_per_frame=3, static=True)
+    rr.close()
+    dev.close()
+
+
+def test_static_entry_point_creates_no_timing_records(ctx):
+    sc = scenes.cornell_box()
+    dev = R.DeviceScene(ctx, sc)
+    rr = R.RenderResources(ctx, 32, 32, dev)
+    cam = R.default_camera(32, 32)
+    ctx.render_times()
+    ctx.phase_times()
+    rr.render(cam, frame=0, static=True)
+    assert ctx.render_times().size == 0
+    assert all(n == 0 for _, n in ctx.phase_times().values())
+    rr.render(cam, frame=1)
+    assert ctx.render_times().size == 1
+    rr.close()
+    dev.close()
