@@ -4,34 +4,91 @@ at 1920x1080, samples-per-pixel sharded over the GPUs of one node.
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (torch.distributed, backend nccl = RCCL). A step is one
-pass of the render hot path over the whole 1080p frame: --spp-per-step
-consecutive dispatches (frame indices) per GPU. GPU g of G renders frame
-indices g, g+G, g+2G, ... into an un-normalised sum; after the last step the
-sums are reduced to rank 0 over RCCL and tone-mapped once. The scene and its
-BVH are resident in HBM before the timed region starts; nothing crosses PCIe
-inside it. Rank 0 prints one JSON line.
+One process per GPU (torch.distributed, backend nccl = RCCL). With --gpus N > 1
+and no WORLD_SIZE in the environment this process only starts the N ranks
+(python -m torch.distributed.run ... bench.py <same arguments>), relays rank
+0's JSON line and exits with the launcher's code; it never touches the GPU
+itself. A step is one pass of the render hot path over the whole frame:
+--spp-per-step consecutive dispatches (frame indices) per GPU (weak scaling), or
+--total-spp dispatches split over the GPUs (strong scaling). In both cases GPU
+g of G renders the step's frame indices g, g+G, g+2G, ... into an un-normalised
+sum; after the last step the sums are reduced to rank 0 over RCCL and tone-mapped
+once. The scene and its BVH are resident in HBM before the timed region starts;
+nothing crosses PCIe inside it. Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Algorithmic bytes: 80 B per wide node visited, 48 B per triangle tested, 84 B
-# per shaded hit (3 indices + 3 positions + 3 normals), 64 B per escaped path
-# (4 RGBA32F texels), 36 B per pixel per dispatch (accumulator read + write,
-# RGBA8 write).
+# Algorithmic bytes: 80 B per wide node fetched (a fetch shared by the lanes of a
+# wave counts once), 48 B per triangle tested, 84 B per shaded hit (3 indices +
+# 3 positions + 3 normals), 64 B per escaped path (4 RGBA32F texels), 36 B per
+# pixel per dispatch (accumulator read + write, RGBA8 write).
 B_NODE, B_TRI, B_HIT, B_MISS, B_PIXEL = 80, 48, 84, 64, 36
 HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth of the 8 XCDs
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=256,
+                    help="dispatches per GPU per step, all in flight at once (the persistent kernel's tail of long "
+                         "paths is paid once per launch); weak scaling")
+    ap.add_argument("--total-spp", type=int, default=0,
+                    help="dispatches per step over ALL GPUs (strong scaling: 4096 with --gpus 8 --steps 1 is the "
+                         "headline configuration as written, 512 per GPU); overrides --spp-per-step")
+    ap.add_argument("--max-paths", type=int, default=0,
+                    help="bound of the wavefront workspace in paths (about 160 B each); 0 = one step's worth")
+    ap.add_argument("--scene", default="dragon",
+                    help="dragon | ref4 | cornell | torus10m | c5 | dragon_small | path of an OBJ / PLY file")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--max-depth", type=int, default=32)
+    ap.add_argument("--integrator", default="wavefront", choices=["megakernel", "wavefront", "stream"])
+    ap.add_argument("--env-res", type=int, default=2048)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-png", default="")
+    ap.add_argument("--wavefront-bounces", type=int, default=0)
+    ap.add_argument("--search-radius", type=int, default=0)
+    ap.add_argument("--two-level", action="store_true",
+                    help="one tree per mesh + instance list instead of one tree over all instanced triangles")
+    return ap.parse_args()
+
+
+def self_launch(n_gpus: int) -> int:
+    """Starts the ranks as children of this (GPU-free) process and relays rank
+    0's JSON line. Nothing here imports torch or touches HIP."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "16")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT)
+    for line in proc.stdout:
+        if line.startswith("{"):
+            sys.stdout.write(line)  # rank 0's result line
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def build_scene(name: str, env_res: int):
@@ -47,6 +104,10 @@ def build_scene(name: str, env_res: int):
                 "reference instance table: 4 x 871,402-triangle knot (diffuse, specular, emissive, dielectric), procedural sky")
     if name == "cornell":
         return scenes.cornell_box(), "Cornell box, 32 triangles, diffuse + emissive"
+    if name == "c5":
+        return (scenes.dragon_in_cornell(scenes.c5_sky_from_hdr(env_res, env_res // 2)),
+                "dragon stand-in (871,402 triangles, specular) inside the Cornell box (walls + light), "
+                "equirectangular sky read from a Radiance .hdr file")
     if name == "torus10m":
         from path_tracer_amd.renderer import IDENTITY, Instance, Scene
         return (Scene([scenes.torus_mesh(3162, 1581)], [Instance(IDENTITY, 0, 0)], sky),
@@ -87,35 +148,32 @@ def cpu_baseline(scene, cam, width, height, max_depth, seconds_target: float):
         "sample": f"{w}x{h}, {n_frames} spp, depth {max_depth}, same scene and camera; "
                   f"{st.rays} rays in {dt:.2f} s (oracle BVH build {build_s:.1f} s not counted)",
         "ms_per_spp_at_full_res": round(dt / n_frames * (width * height) / (w * h) * 1e3, 1),
+        # the reference itself on Mesa lavapipe would be the preferred baseline: neither a Vulkan loader /
+        # ICD, glslc nor the reference's fetched dependencies exist on this machine, so it cannot run here
+        "reference_lavapipe": "unavailable",
+        "oracle_bvh_sah_cost": round(orc.sah_cost(), 2),
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=256,
-                    help="dispatches per GPU per step, all in flight at once (the persistent kernel's tail of long "
-                         "paths is paid once per launch: 64 -> 9.4, 128 -> 9.9, 256 -> 10.2 Grays/s)")
-    ap.add_argument("--max-paths", type=int, default=0,
-                    help="bound of the wavefront workspace in paths (about 160 B each); 0 = one step's worth")
-    ap.add_argument("--scene", default="dragon",
-                    help="dragon | ref4 | cornell | torus10m | dragon_small | path of an OBJ / PLY file")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--max-depth", type=int, default=32)
-    ap.add_argument("--integrator", default="wavefront", choices=["megakernel", "wavefront", "stream"])
-    ap.add_argument("--env-res", type=int, default=2048)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--save-png", default="")
-    ap.add_argument("--wavefront-bounces", type=int, default=0)
-    ap.add_argument("--search-radius", type=int, default=0)
-    ap.add_argument("--two-level", action="store_true",
-                    help="one tree per mesh + instance list instead of one tree over all instanced triangles")
-    args = ap.parse_args()
+def pmc_entry(scene: str, width: int, height: int, spp: int, max_depth: int, kernel: str):
+    """Counter-derived figures of the dominant kernel for this configuration,
+    from the newest profiles/r*_pmc_index.json (written by
+    tools/update_profiles.py from a tools/profile_pmc.sh run); None if that
+    configuration was not profiled."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_index.json")), reverse=True):
+        for e in json.load(open(path)):
+            if (e.get("scene"), e.get("width"), e.get("height"), e.get("spp_per_step"), e.get("max_depth"),
+                    e.get("kernel")) == (scene, width, height, spp, max_depth, kernel):
+                return e
+    return None
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
@@ -123,14 +181,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
+    n_dev = torch.cuda.device_count()  # counting does not initialise the GPU
+    if n_dev < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} GPUs, this machine has {n_dev}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from path_tracer_amd import parallel
     from path_tracer_amd import renderer as R
 
     scene, scene_desc = build_scene(args.scene, args.env_res)
@@ -144,19 +205,23 @@ def main():
                                    search_radius=args.search_radius, two_level=args.two_level)
     rr.max_depth = args.max_depth
     rr.accumulate = R.ACCUM_SUM
-    rr.integrator = R.INTEGRATOR_WAVEFRONT if args.integrator == "wavefront" else R.INTEGRATOR_MEGAKERNEL
     rr.wavefront_bounces = args.wavefront_bounces
+    # dispatches per step: over all ranks, and this rank's share (rank g takes the step's frame indices g, g+G, ...)
+    step_total = args.total_spp if args.total_spp > 0 else args.spp_per_step * world
+    spp = parallel.split_spp(step_total, world)[rank]
+    if step_total < world:
+        raise SystemExit("bench.py: fewer dispatches per step than GPUs")
     # workspace for a whole step in flight: 256 spp at 1080p are 2^29 paths, 85 GB of the 288 GB
     # (bounded by half of the free device memory at about 170 B per path: larger steps run in several batches)
     fits = int(torch.cuda.mem_get_info(local_rank)[0] * 0.5 / 170)
-    rr.max_paths_in_flight = min(args.max_paths or args.spp_per_step * W * H, fits, 2 ** 32 - 1)
+    rr.max_paths_in_flight = min(args.max_paths or spp * W * H, fits, 2 ** 32 - 1)
     info = rr.scene.info
-    spp = args.spp_per_step
+    integrator = {"megakernel": R.INTEGRATOR_MEGAKERNEL, "wavefront": R.INTEGRATOR_WAVEFRONT,
+                  "stream": R.INTEGRATOR_STREAM}[args.integrator]
 
     def step(k: int):
-        # dispatch j of step k on this rank renders frame index (k*spp + j)*world + rank
-        rr.render(cam, frame=k * spp * world + rank, samples_per_frame=1, n_frames=spp,
-                  frame_stride=world)
+        # dispatch j of step k on this rank renders frame index k * step_total + rank + j * world
+        rr.render(cam, frame=k * step_total + rank, samples_per_frame=1, n_frames=spp, frame_stride=world)
 
     def sync_all():
         ctx.synchronize()
@@ -164,24 +229,24 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # Instrumented passes (untimed, megakernel with counters: same rays, same
-    # visit order as the oracle's traversal of this BVH): BVH nodes visited and
-    # triangles tested for all rays and for the first bounce alone; the
-    # difference is what the persistent drain launch has to fetch.
-    def instrumented(depth):
-        rr.integrator, rr.instrument, rr.max_depth = R.INTEGRATOR_MEGAKERNEL, True, depth
+    # Instrumented passes (untimed; counting kernels walk the tree in the same order as the oracle's traversal
+    # of this BVH): nodes visited and triangles tested for all rays and for the first bounce alone with the
+    # megakernel (the difference is what the persistent drain launch has to fetch), and the first bounce again
+    # with the wavefront integrator's own primary kernel, whose waves share most node fetches.
+    def instrumented(integ, depth):
+        rr.integrator, rr.instrument, rr.max_depth = integ, True, depth
         R.reset_render(rr)
         ctx.reset_stats()
         step(0)
         ctx.synchronize()
-        st_ = ctx.stats()
-        return st_.rays, st_.paths, st_.nodes_visited, st_.tris_tested
+        s = ctx.stats()
+        return dict(rays=s.rays, paths=s.paths, nodes=s.nodes_visited, tris=s.tris_tested,
+                    uniform_nodes=s.nodes_wave_uniform, uniform_fetches=s.uniform_fetches)
 
-    inst_all = instrumented(args.max_depth)
-    inst_first = instrumented(1)
-    rr.instrument, rr.max_depth = False, args.max_depth
-    rr.integrator = {"megakernel": R.INTEGRATOR_MEGAKERNEL, "wavefront": R.INTEGRATOR_WAVEFRONT,
-                     "stream": R.INTEGRATOR_STREAM}[args.integrator]
+    inst_all = instrumented(R.INTEGRATOR_MEGAKERNEL, args.max_depth)
+    inst_first = instrumented(R.INTEGRATOR_MEGAKERNEL, 1)
+    inst_primary = instrumented(R.INTEGRATOR_WAVEFRONT, 1) if args.integrator == "wavefront" else inst_first
+    rr.instrument, rr.max_depth, rr.integrator = False, args.max_depth, integrator
     R.reset_render(rr)
 
     for k in range(args.warmup):
@@ -209,7 +274,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = ctx.stats()
-    phases = ctx.phase_times()  # HIP events recorded inside the timed region
+    phases = ctx.phase_times()  # HIP events recorded inside the timed region, on the library's stream
     t = torch.tensor([elapsed, float(st.rays), float(st.paths)], dtype=torch.float64,
                      device=f"cuda:{local_rank}")
     if world > 1:
@@ -225,41 +290,53 @@ def main():
             msg = R.write_to_png(ctx, rr, args.save_png)
             if msg:
                 print(msg, file=sys.stderr)
-        total_spp = args.steps * spp * world
-        rays_a, paths_a, nodes_a, tris_a = inst_all
-        rays_f, _, nodes_f, tris_f = inst_first
+        total_spp = args.steps * step_total
+        A, F1, P = inst_all, inst_first, inst_primary
         # dominant kernel: the one with the largest share of device time
         dom = max(phases, key=lambda k: phases[k][0])
         dom_ms, dom_n = phases[dom]
+        # node bytes: a fetch shared by a wave is billed once (the drain's waves hold unrelated rays and never
+        # share; the primary kernel's and the megakernel's do)
+        node_fetches = lambda c: c["nodes"] - c["uniform_nodes"] + c["uniform_fetches"]
         if dom == "drain":
-            # bounces >= 1 only: the rays, nodes and triangles beyond the first bounce
-            rays_d, nodes_d, tris_d = rays_a - rays_f, nodes_a - nodes_f, tris_a - tris_f
-            # every such ray ends in a shaded hit (84 B gather) or a sky lookup (64 B)
-            alg_bytes = nodes_d * B_NODE + tris_d * B_TRI + rays_d * B_HIT
+            # bounces >= 1 only: the rays, nodes and triangles beyond the first bounce; every such ray ends in
+            # a shaded hit (84 B gather) or a sky lookup (64 B, billed as 84)
+            rays_d, nodes_d, tris_d = A["rays"] - F1["rays"], A["nodes"] - F1["nodes"], A["tris"] - F1["tris"]
+            fetches_d = nodes_d
+            alg_bytes = fetches_d * B_NODE + tris_d * B_TRI + rays_d * B_HIT
+        elif dom == "primary":
+            rays_d, nodes_d, tris_d, fetches_d = P["rays"], P["nodes"], P["tris"], node_fetches(P)
+            # every camera path ends its first bounce in a sky lookup (64 B) or a hit gather (84 B, billed as 64)
+            # and stores its radiance (16 B) or its queue entry (56 B, billed as 16)
+            alg_bytes = fetches_d * B_NODE + tris_d * B_TRI + P["paths"] * (B_MISS + 16)
         else:
-            rays_d, nodes_d, tris_d = rays_a, nodes_a, tris_a
-            alg_bytes = (nodes_d * B_NODE + tris_d * B_TRI + (rays_a - paths_a) * B_HIT + paths_a * B_MISS +
-                         W * H * spp * B_PIXEL)
-        ws_mb = (info.n_nodes * B_NODE + info.n_triangles * B_TRI) / 1e6
+            rays_d, nodes_d, tris_d, fetches_d = A["rays"], A["nodes"], A["tris"], node_fetches(A)
+            alg_bytes = (fetches_d * B_NODE + tris_d * B_TRI + (A["rays"] - A["paths"]) * B_HIT +
+                         A["paths"] * B_MISS + W * H * spp * B_PIXEL)
+        ws_mb = (info.n_nodes * B_NODE + info.n_bvh_triangles * B_TRI) / 1e6
         launches_per_step = max(dom_n // max(args.steps, 1), 1)
         avg_ms = dom_ms / max(dom_n, 1)
         achieved = alg_bytes / launches_per_step / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else float("nan")
-        traffic = l2_hit = None
-        tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("kernel") == dom and tj.get("spp_per_step") == spp and tj.get("scene") == args.scene:
-                traffic = tj.get("hbm_bytes_per_launch")
-                l2_hit = round(tj["l2_hit_rate"], 3) if "l2_hit_rate" in tj else None
+        pmc = pmc_entry(args.scene, W, H, spp, args.max_depth, dom) or {}
+        traffic = pmc.get("hbm_bytes_per_launch")
+        # rates of the two kinds of rays: coherent camera rays (primary pass) and everything after (drain)
+        rate = lambda n_rays, ph: (round(n_rays * args.steps / (phases[ph][0] * 1e-3) / 1e6, 1)
+                                   if phases.get(ph, (0, 0))[0] > 0 else None)
         out = {
             "metric": "Mrays/s (whole node), dragon 1080p", "value": round(total_rays / elapsed / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.total_spp > 0 else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "ms_per_spp": round(elapsed / total_spp * 1e3, 4),
             "reduce_ms": None if reduce_ms is None else round(reduce_ms, 3),
             "rays_per_path": round(total_rays / max(total_paths, 1.0), 3),
-            "config": {"workload": f"{scene_desc}; {W}x{H}, {spp} spp per GPU per step, "
+            "primary_mrays_s": rate(P["rays"], "primary"),
+            "incoherent_mrays_s": rate(A["rays"] - F1["rays"], "drain"),
+            "config": {"workload": f"{scene_desc}; {W}x{H}, {step_total} spp per step over {world} GPU(s) "
+                                   f"({spp} per GPU, all in flight: workspace of {rr.max_paths_in_flight:,} paths = "
+                                   f"{rr.max_paths_in_flight * 160 / 1e9:.0f} GB set through max_paths_in_flight; "
+                                   f"the library's default of 2^27 paths would run 64 dispatches at a time), "
                                    f"max depth {args.max_depth}, {args.integrator}"
                                    f"{', two-level scene' if args.two_level else ''}, spp sharded "
                                    f"over {world} GPU(s), RCCL sum at the end",
@@ -267,17 +344,28 @@ def main():
                        "bvh_build_ms": round(info.build_ms, 2), "bvh_sah_cost": round(info.sah_cost, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "l2_hit_rate": l2_hit,
+                         # what the memory system beyond L2 actually moved, and the algorithmic rate against the
+                         # level that serves most fetches of a cache-resident working set
+                         "hbm_traffic_frac": (round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                              if traffic else None),
+                         "l2_frac": round(achieved / L2_PEAK_GBS, 4),
+                         "l2_hit_rate": pmc.get("l2_hit_rate"),
+                         "td_busy": pmc.get("td_busy"), "ta_busy": pmc.get("ta_busy"),
+                         "lane_util": pmc.get("lane_util"), "valu_busy": pmc.get("valu_busy"),
+                         "pmc_source": pmc.get("source"),
                          "kernel": dom, "avg_launch_ms": round(avg_ms, 3),
                          "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": int(alg_bytes / launches_per_step),
                          "rays_per_launch": int(rays_d / launches_per_step),
                          "nodes_per_ray": round(nodes_d / max(rays_d, 1), 2),
+                         "node_fetches_per_ray": round(fetches_d / max(rays_d, 1), 2),
                          "tris_per_ray": round(tris_d / max(rays_d, 1), 2),
                          "phase_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in phases.items() if v[1]},
                          "note": f"node + triangle working set {ws_mb:.0f} MB "
-                                 + ("fits the 256 MB Infinity Cache; HBM peak is the stated bound, not the "
-                                    "level that serves the fetches" if ws_mb < 256 else
+                                 + ("fits the 256 MB Infinity Cache: HBM peak is the contract's stated bound, but "
+                                    "L2 and the Infinity Cache serve the fetches (see hbm_traffic_frac, l2_frac); "
+                                    "the kernel is bound by the per-CU vector-memory return path (td_busy) and "
+                                    "lane utilisation, not by bytes" if ws_mb < 256 else
                                     "exceeds the 256 MB Infinity Cache: HBM serves the misses")},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -194,7 +194,11 @@ typedef struct ptc_render_params
     float tmax;                  /* the literal 10000.0 of shader.rgen:77 (0 -> 10000) */
     uint32_t integrator;         /* PTC_INTEGRATOR_* */
     uint32_t accumulate;         /* PTC_ACCUM_* */
-    uint32_t instrument;         /* 1: also count BVH nodes / triangles visited */
+    /* 1: also count BVH nodes / triangles visited. Megakernel: all bounces.
+     * Wavefront: the fused first bounce only (the persistent launch that
+     * follows counts rays, nothing else). Stream: ignored. Counting runs use
+     * the reproducible visit order, so they are slower than plain ones. */
+    uint32_t instrument;
     /* Wavefront integrator: bounces after the first that run as separate
      * traversal / shading launches over compacted queues before one persistent
      * launch finishes the remaining paths. 0 (default, fastest measured): the
@@ -223,6 +227,12 @@ typedef struct ptc_stats
     uint64_t nodes_visited; /* counted only by instrumented calls */
     uint64_t tris_tested;
     double render_ms; /* device time of the last ptc_render */
+    /* Of nodes_visited: visits whose 80-byte node was fetched once for all lanes
+     * of the wave that were at that node together (through the scalar cache),
+     * and the number of such shared fetches. Bytes actually requested for nodes
+     * = 80 * (nodes_visited - nodes_wave_uniform + uniform_fetches). */
+    uint64_t nodes_wave_uniform;
+    uint64_t uniform_fetches;
 } ptc_stats;
 
 /* ---- context: stands in for create_context() (src/renderer.hpp:256) ------ */

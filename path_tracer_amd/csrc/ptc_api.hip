@@ -849,7 +849,8 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
     ctx->no_events = static_scratch;
     if (integrator != PTC_INTEGRATOR_MEGAKERNEL)
     {
-        rc = launch_render_wavefront(ctx, scene, film, F, integrator == PTC_INTEGRATOR_STREAM, static_scratch);
+        rc = launch_render_wavefront(ctx, scene, film, F, integrator == PTC_INTEGRATOR_STREAM, static_scratch,
+                                     params->instrument != 0);
     }
     else
     {
@@ -1007,6 +1008,8 @@ int ptc_trace_rays(ptc_context *ctx, const ptc_scene *scene, const float *rays, 
         counters->rays += n_rays;
         counters->nodes_visited += after.nodes - before.nodes;
         counters->tris_tested += after.tris - before.tris;
+        counters->nodes_wave_uniform += after.uniform_nodes - before.uniform_nodes;
+        counters->uniform_fetches += after.uniform_fetches - before.uniform_fetches;
     }
     return rc;
 }
@@ -1038,6 +1041,8 @@ int ptc_get_stats(ptc_context *ctx, ptc_stats *out)
     out->paths = s.paths;
     out->nodes_visited = s.nodes;
     out->tris_tested = s.tris;
+    out->nodes_wave_uniform = s.uniform_nodes;
+    out->uniform_fetches = s.uniform_fetches;
     out->render_ms = ctx->last_render_ms;
     return PTC_OK;
 }

@@ -556,6 +556,11 @@ struct TraceCounters
 {
     uint32_t nodes;
     uint32_t tris;
+    // node visits served by a fetch shared with the rest of the wave (through the
+    // scalar cache), and the number of such fetches: a wave of 64 lanes at one
+    // node adds 64 to the first and 1 to the second
+    uint32_t uniform_nodes;
+    uint32_t uniform_fetches;
 };
 
 PTC_DEV float ubyte_f(uint32_t w, int i)
@@ -716,7 +721,7 @@ PTC_DEV void node_eval(const uint4 w0, const uint4 w1, const uint4 w2, const uin
 // wave-uniform node (kernels whose waves hold unrelated rays almost never pass it).
 template <bool kTryUniform = true>
 PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t node_idx, uint2 &ng,
-                       uint2 &tg)
+                       uint2 &tg, TraceCounters *ctr = nullptr)
 {
     // When every active lane of the wave visits the same node (the root always;
     // camera rays of one pixel nearly always), fetch it once through the scalar
@@ -730,6 +735,13 @@ PTC_DEV void node_test(const DScene &S, const RayCtx &R, float best_t, uint32_t 
         typedef const __attribute__((address_space(4))) u32x4 *scalar_ptr;
         const scalar_ptr N = (scalar_ptr)(uintptr_t)(S.nodes + 5u * (size_t)first_idx);
         const u32x4 s0 = N[0], s1 = N[1], s2 = N[2], s3 = N[3], s4 = N[4];
+        if (ctr != nullptr)
+        {
+            ctr->uniform_nodes++;
+            const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+            const uint32_t me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            ctr->uniform_fetches += me == (uint32_t)__builtin_ctzll(active) ? 1u : 0u;
+        }
         const uint4 w0 = make_uint4(s0.x, s0.y, s0.z, s0.w), w1 = make_uint4(s1.x, s1.y, s1.z, s1.w);
         const uint4 w2 = make_uint4(s2.x, s2.y, s2.z, s2.w), w3 = make_uint4(s3.x, s3.y, s3.z, s3.w);
         const uint4 w4 = make_uint4(s4.x, s4.y, s4.z, s4.w);
@@ -839,7 +851,7 @@ PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *ld
             stack_push<kLds>(lds_stack, stride, spill, sp, ng);
         }
         uint2 tg;
-        node_test(S, R, best.t, node_idx, ng, tg);
+        node_test(S, R, best.t, node_idx, ng, tg, kCount ? ctr : nullptr);
         if (kCount)
         {
             ctr->nodes++;

@@ -33,6 +33,8 @@ struct DeviceStats
     unsigned long long paths;
     unsigned long long nodes;
     unsigned long long tris;
+    unsigned long long uniform_nodes;
+    unsigned long long uniform_fetches;
 };
 
 } // namespace ptc
@@ -150,8 +152,9 @@ int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
 // static_scratch: the workspace is the library's static device array instead of
 // ctx->wf_buf; nothing is allocated, freed or synchronised, and a call whose
 // single dispatch does not fit returns PTC_E_LIMIT.
+// count: the fused first-bounce kernel also counts nodes / triangles visited.
 int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
-                            const DFrame &frame, bool stream, bool static_scratch);
+                            const DFrame &frame, bool stream, bool static_scratch, bool count);
 // Looks up the device address of the static array on ctx's (current) device.
 int wavefront_static_init(ptc_context *ctx);
 int launch_primary_hits(ptc_context *ctx, const ptc_scene *scene, const DFrame &frame,

@@ -33,9 +33,7 @@ k_render_mega(DScene S, DFrame F, float4 *__restrict__ accum, uint32_t *__restri
     const uint32_t px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
     uint32_t rays = 0, paths = 0;
-    TraceCounters ctr;
-    ctr.nodes = 0;
-    ctr.tris = 0;
+    TraceCounters ctr = {0u, 0u, 0u, 0u};
     if (px < F.width && py < F.height)
     {
         const uint32_t pixel_index = py * F.width + px;
@@ -83,10 +81,13 @@ k_render_mega(DScene S, DFrame F, float4 *__restrict__ accum, uint32_t *__restri
     if (kCount)
     {
         const unsigned long long wn = wave_sum_u64(ctr.nodes), wt = wave_sum_u64(ctr.tris);
+        const unsigned long long wu = wave_sum_u64(ctr.uniform_nodes), wf = wave_sum_u64(ctr.uniform_fetches);
         if (lane == 0u)
         {
             atomicAdd(&stats->nodes, wn);
             atomicAdd(&stats->tris, wt);
+            atomicAdd(&stats->uniform_nodes, wu);
+            atomicAdd(&stats->uniform_fetches, wf);
         }
     }
 }
@@ -117,9 +118,7 @@ k_trace(DScene S, const float *__restrict__ rays, size_t n, float tmax, ptc_hit 
 {
     __shared__ uint2 s_stack[kLdsStack * kBlock];
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    TraceCounters ctr;
-    ctr.nodes = 0;
-    ctr.tris = 0;
+    TraceCounters ctr = {0u, 0u, 0u, 0u};
     if (i < n)
     {
         const vec3 o = v3(rays[6 * i + 0], rays[6 * i + 1], rays[6 * i + 2]);
@@ -139,10 +138,13 @@ k_trace(DScene S, const float *__restrict__ rays, size_t n, float tmax, ptc_hit 
     if (kCount)
     {
         const unsigned long long wn = wave_sum_u64(ctr.nodes), wt = wave_sum_u64(ctr.tris);
+        const unsigned long long wu = wave_sum_u64(ctr.uniform_nodes), wf = wave_sum_u64(ctr.uniform_fetches);
         if ((threadIdx.x & 63u) == 0u)
         {
             atomicAdd(&stats->nodes, wn);
             atomicAdd(&stats->tris, wt);
+            atomicAdd(&stats->uniform_nodes, wu);
+            atomicAdd(&stats->uniform_fetches, wf);
         }
     }
 }

@@ -146,11 +146,13 @@ PTC_DEV PathState camera_path(const DFrame &F, uint32_t px, uint32_t py, uint32_
 }
 
 constexpr int kPrimaryLds = 8; // LDS stack entries per lane: 16 KB per block, so registers (not LDS) set the occupancy
-template <bool kPixelMajor, bool kTwoLevel>
+// kCount: also count nodes / triangles visited (reproducible visit order, slower).
+template <bool kPixelMajor, bool kTwoLevel, bool kCount>
 __global__ void __launch_bounds__(kBlock)
 k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample,
-             uint32_t n_disp, uint32_t lane_bits)
+             uint32_t n_disp, uint32_t lane_bits, DeviceStats *__restrict__ stats)
 {
+    TraceCounters ctr = {0u, 0u, 0u, 0u};
     __shared__ uint2 s_stack[kPrimaryLds * kBlock];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tiles_x = (F.width + 15u) >> 4;
@@ -215,8 +217,8 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
             Hit h = no_hit(F.tmax);
             if (kTwoLevel || ray_meets_box(S.box_lo, S.box_hi, ps.origin, ps.dir, F.tmax))
             {
-                h = trace_scene<false, kTwoLevel, kPrimaryLds>(S, ps.origin, ps.dir, F.tmax, s_stack + threadIdx.x,
-                                                               kBlock, nullptr);
+                h = trace_scene<kCount, kTwoLevel, kPrimaryLds>(S, ps.origin, ps.dir, F.tmax, s_stack + threadIdx.x,
+                                                                kBlock, &ctr);
             }
             alive = path_bounce(S, h, ps) && F.max_depth > 1u;
         }
@@ -250,6 +252,24 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
             slot += s_alive[w];
         }
         store_state(B.q[1], slot, ps, pid);
+    }
+    if (kCount)
+    {
+        unsigned long long v[4] = {ctr.nodes, ctr.tris, ctr.uniform_nodes, ctr.uniform_fetches};
+        for (int k = 0; k < 4; ++k)
+        {
+            for (int off = 32; off > 0; off >>= 1)
+            {
+                v[k] += __shfl_xor(v[k], off, 64);
+            }
+        }
+        if (lane == 0u)
+        {
+            atomicAdd(&stats->nodes, v[0]);
+            atomicAdd(&stats->tris, v[1]);
+            atomicAdd(&stats->uniform_nodes, v[2]);
+            atomicAdd(&stats->uniform_fetches, v[3]);
+        }
     }
 }
 
@@ -713,7 +733,7 @@ int wavefront_static_init(ptc_context *ctx)
 // as successive passes, each pass starting from the state the previous sample
 // of the same pixel ended with.
 int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &F0,
-                            bool stream, bool static_scratch)
+                            bool stream, bool static_scratch, bool count)
 {
     hipStream_t st = ctx->stream;
     const uint32_t n_pixels = F0.width * F0.height;
@@ -849,32 +869,38 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
                         lane_bits = bits;
                     }
                 }
+                // kernel variant by (pixel-major mapping, two-level scene, counting)
+                auto launch = [&](auto kernel, uint32_t grid, uint32_t bits) {
+                    kernel<<<grid, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0, s, nb, bits, ctx->d_stats);
+                };
                 if (nb >= 16u)
                 {
                     const uint32_t pixel_blocks = (tiles * 256u) / (kBlock >> lane_bits);
                     const uint32_t k_groups = (nb + (1u << lane_bits) - 1u) >> lane_bits;
-                    if (two_level)
+                    const uint32_t grid = pixel_blocks * k_groups;
+                    if (count)
                     {
-                        k_wf_primary<true, true><<<pixel_blocks * k_groups, kBlock, 0, st>>>(
-                            scene->d, F0, B, F0.global_frame_count, k0, s, nb, lane_bits);
+                        two_level ? launch(k_wf_primary<true, true, true>, grid, lane_bits)
+                                  : launch(k_wf_primary<true, false, true>, grid, lane_bits);
                     }
                     else
                     {
-                        k_wf_primary<true, false><<<pixel_blocks * k_groups, kBlock, 0, st>>>(
-                            scene->d, F0, B, F0.global_frame_count, k0, s, nb, lane_bits);
+                        two_level ? launch(k_wf_primary<true, true, false>, grid, lane_bits)
+                                  : launch(k_wf_primary<true, false, false>, grid, lane_bits);
                     }
                 }
                 else
                 {
-                    if (two_level)
+                    const uint32_t grid = tiles * nb;
+                    if (count)
                     {
-                        k_wf_primary<false, true><<<tiles * nb, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count,
-                                                                                k0, s, nb, 0u);
+                        two_level ? launch(k_wf_primary<false, true, true>, grid, 0u)
+                                  : launch(k_wf_primary<false, false, true>, grid, 0u);
                     }
                     else
                     {
-                        k_wf_primary<false, false><<<tiles * nb, kBlock, 0, st>>>(scene->d, F0, B,
-                                                                                 F0.global_frame_count, k0, s, nb, 0u);
+                        two_level ? launch(k_wf_primary<false, true, false>, grid, 0u)
+                                  : launch(k_wf_primary<false, false, false>, grid, 0u);
                     }
                 }
             }

@@ -109,7 +109,8 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("nodes_visited", C.c_uint64),
-                ("tris_tested", C.c_uint64), ("render_ms", C.c_double)]
+                ("tris_tested", C.c_uint64), ("render_ms", C.c_double),
+                ("nodes_wave_uniform", C.c_uint64), ("uniform_fetches", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("flat", "<u4")])

@@ -32,7 +32,13 @@ def test_bench_line_has_the_contract_fields():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # fetches shared by a wave are billed once: no more node fetches than node visits
+    assert 0 < r["node_fetches_per_ray"] <= r["nodes_per_ray"]
+    for key in ("hbm_traffic_frac", "l2_frac", "td_busy", "lane_util"):
+        assert key in r, key
+    assert j["primary_mrays_s"] > 0 and j["incoherent_mrays_s"] > 0
     c = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    assert c["reference_lavapipe"] == "unavailable"

@@ -66,3 +66,71 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
         env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "GPU_PARALLEL_OK" in out.stdout
+
+
+NCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["PT_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from path_tracer_amd import parallel, renderer as R, scenes
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+ctx = R.create_context(0)
+sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+w, h, spp = 128, 72, 5
+cam = R.default_camera(w, h)
+accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+torch.cuda.synchronize()
+rr = R.create_render_resources(ctx, w, h, sc, accum_dev=accum.data_ptr())
+rr.accumulate = R.ACCUM_SUM
+rr.max_depth = 6
+f0, stride, n = parallel.frame_schedule(0, 1, 3, spp)
+rr.render(cam, frame=f0, n_frames=n, frame_stride=stride)
+ctx.synchronize()
+before = accum.clone()
+# the collectives bench.py issues, on the film's own device memory, through RCCL
+dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+t = torch.tensor([1.5, 2.0], dtype=torch.float64, device="cuda:0")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(accum, before) and t.tolist() == [1.5, 2.0]   # one rank: the sum is the rank's own film
+rr.resolve(sum_mode=True)
+img = rr.read_rgba8()
+single = R.create_render_resources(ctx, w, h, sc)
+single.max_depth = 6
+single.render(cam, frame=3, n_frames=spp)
+assert np.abs(img.astype(int) - single.read_rgba8().astype(int)).max() <= 1
+assert (accum[..., 3] == spp).all()
+print("NCCL_WS1_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_backend_reduces_the_film_in_place_with_one_rank(tmp_path):
+    """The nccl (= RCCL) code path of bench.py on the one GPU a test box has:
+    process group of one rank, reduce / all_reduce / barrier on device tensors,
+    the film's accumulator among them, then the resolve."""
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, PT_ROOT=ROOT)
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+         "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "NCCL_WS1_OK" in out.stdout
+
+
+def test_bench_strong_scaling_line_on_one_gpu():
+    """--total-spp on one GPU: the line says "strong" and the step renders exactly that many dispatches."""
+    import json
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--scene", "dragon_small", "--width", "160", "--height", "90",
+         "--total-spp", "6", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"],
+        capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 1
+    assert abs(j["ms_per_spp"] * 12 - j["ms_per_step"] * 2) < 1e-2 * j["ms_per_step"] + 1e-3

@@ -62,3 +62,29 @@ def test_two_rank_gloo_reduce_matches_single_process(tmp_path):
         env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "PARALLEL_OK" in out.stdout
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_fails_cleanly_without_the_gpus():
+    """`python bench.py --gpus 2` typed as is (no launcher, no WORLD_SIZE) starts two
+    ranks itself; on a machine with fewer than 2 GPUs every rank says so and the
+    parent returns the launcher's non-zero code without a JSON line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("machine has 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "needs 2 GPUs" in out.stderr, out.stderr[-2000:]
+    assert "launch with torch.distributed.run" not in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_strong_scaling_split_covers_the_step_once():
+    """--total-spp: rank g of G renders frames g, g+G, ... of the step's T frame
+    indices, split_spp(T, G)[g] of them; the union is 0..T-1 exactly once."""
+    for total, world in ((4096, 8), (10, 4), (7, 2), (5, 5)):
+        counts = parallel.split_spp(total, world)
+        frames = sorted(r + j * world for r in range(world) for j in range(counts[r]))
+        assert frames == list(range(total))

@@ -1,43 +1,68 @@
 #!/usr/bin/env python3
 """Copies the judged evidence of one tools/profile_pmc.sh run into profiles/:
-the kernel-trace statistics, the per-kernel counter summary, and the HBM-side
-traffic of the dominant kernel that bench.py reports as roofline.traffic.
-Usage: update_profiles.py <gpurun_out/dir> <tag, e.g. r01> [spp_per_step]"""
+the kernel-trace statistics, the per-kernel counter summary, and one entry per
+render kernel in profiles/<tag>_pmc_index.json, which bench.py reads for
+roofline.traffic and the counter-derived fields beside it.
+
+Usage: update_profiles.py <gpurun_out/dir> <tag, e.g. r02> <label, e.g. dragon1080p>
+           [--scene dragon --width 1920 --height 1080 --spp 256 --max-depth 32]
+"""
+import argparse
 import glob
 import json
 import os
 import shutil
-import sys
 
-src, tag = sys.argv[1], sys.argv[2]
-spp = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+ap = argparse.ArgumentParser()
+ap.add_argument("src")
+ap.add_argument("tag")
+ap.add_argument("label")
+ap.add_argument("--scene", default="dragon")
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--spp", type=int, default=256)
+ap.add_argument("--max-depth", type=int, default=32)
+ap.add_argument("--cus", type=int, default=256)
+a = ap.parse_args()
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
-shutil.copy(stats, os.path.join(dst, f"{tag}_wavefront_dragon1080p_kernel_stats.csv"))
-summary = json.load(open(os.path.join(src, "summary.json")))
-json.dump(summary, open(os.path.join(dst, f"{tag}_wavefront_dragon1080p_pmc_summary.json"), "w"), indent=1,
-          sort_keys=True)
-kernels = summary["kernels"]
-name = max(("k_wf_drain", "k_wf_primary"), key=lambda k: kernels[k]["total_ms"])
-k = kernels[name]
-fetch_kb, write_kb = k["FETCH_SIZE_per_dispatch"], k["WRITE_SIZE_per_dispatch"]
-out = {
-    "kernel": name.replace("k_wf_", ""),
-    "kernel_symbol": name,
-    "scene": "dragon",
-    "spp_per_step": spp,
-    "mean_launch_us": k["mean_us"],
-    "FETCH_SIZE_KB_per_launch": fetch_kb,
-    "WRITE_SIZE_KB_per_launch": write_kb,
-    # FETCH_SIZE tallies the 128-byte fabric requests of 16-byte-per-lane loads at 64 bytes on gfx950
-    "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
-    "l2_hit_rate": k["TCC_HIT_sum_per_dispatch"] / k["TCC_REQ_sum_per_dispatch"],
-    "method": "rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum and --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum in separate "
-              "passes (tools/profile_pmc.sh); FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B; "
-              "uncalibrated for scattered loads); the counters sit on the L2's memory side and include "
-              "Infinity-Cache hits, so this is traffic beyond L2, an upper bound on HBM traffic",
-    "source": f"profiles/{tag}_wavefront_dragon1080p_pmc_summary.json",
-}
-json.dump(out, open(os.path.join(dst, f"{tag}_dominant_kernel_traffic.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
+stats = glob.glob(os.path.join(a.src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(stats, os.path.join(dst, f"{a.tag}_{a.label}_kernel_stats.csv"))
+summary = json.load(open(os.path.join(a.src, "summary.json")))
+summary_name = f"{a.tag}_{a.label}_pmc_summary.json"
+json.dump(summary, open(os.path.join(dst, summary_name), "w"), indent=1, sort_keys=True)
+
+index_path = os.path.join(dst, f"{a.tag}_pmc_index.json")
+index = json.load(open(index_path)) if os.path.exists(index_path) else []
+for symbol, short in (("k_wf_drain", "drain"), ("k_wf_primary", "primary"), ("k_render_mega", "megakernel")):
+    k = summary["kernels"].get(symbol)
+    if not k or "FETCH_SIZE_per_dispatch" not in k:
+        continue
+    fetch_kb, write_kb = k["FETCH_SIZE_per_dispatch"], k["WRITE_SIZE_per_dispatch"]
+    cycles = k.get("GRBM_GUI_ACTIVE_per_dispatch") or 0.0
+    entry = {
+        "scene": a.scene, "width": a.width, "height": a.height, "spp_per_step": a.spp, "max_depth": a.max_depth,
+        "kernel": short, "kernel_symbol": symbol, "mean_launch_us": k["mean_us"],
+        "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+        # FETCH_SIZE tallies the 128-byte fabric requests of 16-byte-per-lane loads at 64 bytes on gfx950
+        "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+        "l2_hit_rate": round(k["TCC_HIT_sum_per_dispatch"] / k["TCC_REQ_sum_per_dispatch"], 4),
+        # busy cycles summed over the CUs' texture-data / texture-address units against CUs x kernel cycles
+        "td_busy": round(k["TD_TD_BUSY_sum_per_dispatch"] / (a.cus * cycles), 4) if cycles else None,
+        "ta_busy": round(k["TA_TA_BUSY_sum_per_dispatch"] / (a.cus * cycles), 4) if cycles else None,
+        # active lanes per VALU instruction issued, of 64
+        "lane_util": round(k["SQ_THREAD_CYCLES_VALU_per_dispatch"] / (64.0 * k["SQ_ACTIVE_INST_VALU_per_dispatch"]), 4),
+        # cycles a SIMD spends issuing VALU work, of the cycles the CUs' 4 SIMDs had
+        "valu_busy": round(k["SQ_ACTIVE_INST_VALU_per_dispatch"] / (4.0 * a.cus * cycles), 4) if cycles else None,
+        "vmem_wave_insts_per_launch": k.get("SQ_INSTS_VMEM_RD_per_dispatch"),
+        "method": "rocprofv3 --pmc, one pass per counter group (tools/profile_pmc.sh); FETCH_SIZE doubled (gfx950 "
+                  "counts 128-B requests as 64 B; uncalibrated for scattered loads); FETCH/WRITE_SIZE sit on the "
+                  "L2's memory side and include Infinity-Cache hits: traffic beyond L2, an upper bound on HBM traffic",
+        "source": f"profiles/{summary_name}",
+    }
+    index = [e for e in index if (e["scene"], e["width"], e["height"], e["spp_per_step"], e["max_depth"], e["kernel"]) !=
+             (a.scene, a.width, a.height, a.spp, a.max_depth, short)]
+    index.append(entry)
+    print(json.dumps(entry, indent=1))
+json.dump(index, open(index_path, "w"), indent=1)
