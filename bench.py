@@ -151,7 +151,8 @@ def cpu_baseline(scene, cam, width, height, max_depth, seconds_target: float):
         # the reference itself on Mesa lavapipe would be the preferred baseline: neither a Vulkan loader /
         # ICD, glslc nor the reference's fetched dependencies exist on this machine, so it cannot run here
         "reference_lavapipe": "unavailable",
-        "oracle_bvh_sah_cost": round(orc.sah_cost(), 2),
+        # yardstick for config.bvh_sah_cost: the same cost for the 8-wide collapse of a top-down binned-SAH tree
+        "oracle_wide_sah_cost": round(orc.wide_sah_cost()[0], 2),
     }
 
 

@@ -827,6 +827,7 @@ typedef struct
     float *pcen; /* 3 per prim */
     uint32_t cap;
     float pad; /* absolute box padding covering Moller-Trumbore rounding slop */
+    uint32_t leaf_max; /* most triangles a leaf may hold */
 } build_ctx;
 
 static uint32_t build_rec(build_ctx *B, uint32_t first, uint32_t count)
@@ -847,7 +848,7 @@ static uint32_t build_rec(build_ctx *B, uint32_t first, uint32_t count)
     const double pa = box_area(&nb);
     int best_axis = -1, best_bin = 0;
     /* leaf cost (Ct = 1, Cn = 1); nodes too big for a leaf must split */
-    double best_cost = count > BVH_LEAF_MAX ? INFINITY : (double)count;
+    double best_cost = count > B->leaf_max ? INFINITY : (double)count;
     if (count > 1)
     {
         for (int ax = 0; ax < 3; ++ax)
@@ -908,7 +909,7 @@ static uint32_t build_rec(build_ctx *B, uint32_t first, uint32_t count)
             }
         }
     }
-    if (best_axis < 0 && count > BVH_LEAF_MAX)
+    if (best_axis < 0 && count > B->leaf_max)
     {
         /* all centroids coincide: split in the middle */
         const uint32_t half = count / 2;
@@ -955,6 +956,51 @@ static uint32_t build_rec(build_ctx *B, uint32_t first, uint32_t count)
     return me;
 }
 
+/* padded boxes and centres of all flattened triangles */
+static void prepare_prims(pt_scene *S, build_ctx *B)
+{
+    const uint32_t n = S->n_tris;
+    B->S = S;
+    B->pbox = (box_t *)malloc(n * sizeof(box_t));
+    B->pcen = (float *)malloc((size_t)n * 12);
+    box_t sb;
+    box_empty(&sb);
+    for (uint32_t g = 0; g < n; ++g)
+    {
+        const wtri_t *T = &S->tris[g];
+        const float a[3] = {T->v0.x, T->v0.y, T->v0.z};
+        const float b[3] = {T->v0.x + T->e1.x, T->v0.y + T->e1.y,
+                            T->v0.z + T->e1.z};
+        const float c[3] = {T->v0.x + T->e2.x, T->v0.y + T->e2.y,
+                            T->v0.z + T->e2.z};
+        box_t *pb = &B->pbox[g];
+        box_empty(pb);
+        box_grow_pt(pb, a);
+        box_grow_pt(pb, b);
+        box_grow_pt(pb, c);
+        for (int k = 0; k < 3; ++k)
+        {
+            B->pcen[3 * g + k] = 0.5f * (pb->lo[k] + pb->hi[k]);
+        }
+        box_grow(&sb, pb);
+        S->prim_order[g] = g;
+    }
+    float mag = 0.0f;
+    for (int k = 0; k < 3; ++k)
+    {
+        mag = pt_max(mag, pt_max(fabsf(sb.lo[k]), fabsf(sb.hi[k])));
+    }
+    B->pad = mag * (1.0f / 262144.0f);
+    for (uint32_t g = 0; g < n; ++g)
+    {
+        for (int k = 0; k < 3; ++k)
+        {
+            B->pbox[g].lo[k] -= B->pad;
+            B->pbox[g].hi[k] += B->pad;
+        }
+    }
+}
+
 static void build_bvh(pt_scene *S)
 {
     const uint32_t n = S->n_tris;
@@ -967,45 +1013,8 @@ static void build_bvh(pt_scene *S)
         return;
     }
     build_ctx B;
-    B.S = S;
-    B.pbox = (box_t *)malloc(n * sizeof(box_t));
-    B.pcen = (float *)malloc((size_t)n * 12);
-    box_t sb;
-    box_empty(&sb);
-    for (uint32_t g = 0; g < n; ++g)
-    {
-        const wtri_t *T = &S->tris[g];
-        const float a[3] = {T->v0.x, T->v0.y, T->v0.z};
-        const float b[3] = {T->v0.x + T->e1.x, T->v0.y + T->e1.y,
-                            T->v0.z + T->e1.z};
-        const float c[3] = {T->v0.x + T->e2.x, T->v0.y + T->e2.y,
-                            T->v0.z + T->e2.z};
-        box_t *pb = &B.pbox[g];
-        box_empty(pb);
-        box_grow_pt(pb, a);
-        box_grow_pt(pb, b);
-        box_grow_pt(pb, c);
-        for (int k = 0; k < 3; ++k)
-        {
-            B.pcen[3 * g + k] = 0.5f * (pb->lo[k] + pb->hi[k]);
-        }
-        box_grow(&sb, pb);
-        S->prim_order[g] = g;
-    }
-    float mag = 0.0f;
-    for (int k = 0; k < 3; ++k)
-    {
-        mag = pt_max(mag, pt_max(fabsf(sb.lo[k]), fabsf(sb.hi[k])));
-    }
-    B.pad = mag * (1.0f / 262144.0f);
-    for (uint32_t g = 0; g < n; ++g)
-    {
-        for (int k = 0; k < 3; ++k)
-        {
-            B.pbox[g].lo[k] -= B.pad;
-            B.pbox[g].hi[k] += B.pad;
-        }
-    }
+    prepare_prims(S, &B);
+    B.leaf_max = BVH_LEAF_MAX;
     build_rec(&B, 0, n);
     /* SAH cost: sum over internal nodes of A/Aroot + leaves A/Aroot * count */
     box_t rb;
@@ -1024,6 +1033,124 @@ static void build_bvh(pt_scene *S)
     S->sah_cost = cost;
     free(B.pbox);
     free(B.pcen);
+}
+
+/* --- yardstick for a device-built wide tree ---------------------------------
+ * The shipped library builds an 8-wide tree (bottom-up clustering, collapse,
+ * leaf slots of <= 3 triangles). To judge its quality on the same scale, the
+ * oracle builds a top-down binned-SAH binary tree down to single triangles,
+ * collapses it by the same rule (open the child of largest area until 8 slots
+ * are used; children with <= 3 triangles become leaf slots) and evaluates the
+ * same cost: 1 for the root, A/A_root per internal slot, A/A_root * triangles
+ * per leaf slot, with the exact (unquantised) float boxes. */
+
+static uint32_t subtree_count(const bnode_t *N, uint32_t i, uint32_t *cnt)
+{
+    if (N[i].count)
+    {
+        cnt[i] = N[i].count;
+    }
+    else
+    {
+        cnt[i] = subtree_count(N, N[i].left, cnt) + subtree_count(N, N[i].right, cnt);
+    }
+    return cnt[i];
+}
+
+static double node_area(const bnode_t *n)
+{
+    box_t b;
+    memcpy(b.lo, n->lo, 12);
+    memcpy(b.hi, n->hi, 12);
+    return box_area(&b);
+}
+
+static double wide_cost_rec(const bnode_t *N, const uint32_t *cnt, uint32_t root, double root_area,
+                            uint32_t leaf_max, uint64_t *n_wide)
+{
+    uint32_t child[8];
+    uint32_t n = 0;
+    ++*n_wide;
+    if (N[root].count)
+    {
+        child[n++] = root;
+    }
+    else
+    {
+        child[n++] = N[root].left;
+        child[n++] = N[root].right;
+        while (n < 8)
+        {
+            int pick = -1;
+            double best = -1.0;
+            for (uint32_t k = 0; k < n; ++k)
+            {
+                const double a = N[child[k]].count ? -1.0 : node_area(&N[child[k]]);
+                if (a > best)
+                {
+                    best = a;
+                    pick = (int)k;
+                }
+            }
+            if (pick < 0)
+            {
+                break;
+            }
+            const uint32_t c = child[pick];
+            child[pick] = N[c].left;
+            child[n++] = N[c].right;
+        }
+    }
+    double cost = 0.0;
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        const double a = node_area(&N[child[k]]) / root_area;
+        if (cnt[child[k]] > leaf_max)
+        {
+            cost += a + wide_cost_rec(N, cnt, child[k], root_area, leaf_max, n_wide);
+        }
+        else
+        {
+            cost += a * cnt[child[k]];
+        }
+    }
+    return cost;
+}
+
+double pt_scene_wide_sah_cost(const pt_scene *S, uint64_t *n_wide_nodes)
+{
+    const uint32_t n = S->n_tris;
+    if (n_wide_nodes)
+    {
+        *n_wide_nodes = 0;
+    }
+    if (n == 0)
+    {
+        return 1.0;
+    }
+    pt_scene T = *S; /* shares the triangles; owns its own tree */
+    T.nodes = (bnode_t *)calloc(2 * (size_t)n, sizeof(bnode_t));
+    T.prim_order = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    T.n_nodes = 0;
+    build_ctx B;
+    prepare_prims(&T, &B);
+    B.leaf_max = 1;
+    build_rec(&B, 0, n);
+    uint32_t *cnt = (uint32_t *)calloc(T.n_nodes, sizeof(uint32_t));
+    subtree_count(T.nodes, 0, cnt);
+    const double ra = node_area(&T.nodes[0]);
+    uint64_t n_wide = 0;
+    const double cost = 1.0 + wide_cost_rec(T.nodes, cnt, 0, ra > 0 ? ra : 1.0, 3, &n_wide);
+    if (n_wide_nodes)
+    {
+        *n_wide_nodes = n_wide;
+    }
+    free(cnt);
+    free(B.pbox);
+    free(B.pcen);
+    free(T.nodes);
+    free(T.prim_order);
+    return cost;
 }
 
 /* --- traversal of the oracle's own BVH -------------------------------------*/

@@ -137,6 +137,11 @@ void pt_scene_triangle_ids(const pt_scene *scene, uint32_t flat,
 void pt_scene_world_triangles(const pt_scene *scene, float *out);
 void pt_miss(const pt_scene *scene, const float dir[3], float out_color[3]);
 double pt_scene_bvh_sah_cost(const pt_scene *scene);
+/* SAH cost (Ct = Cn = 1) of the 8-wide tree obtained from a top-down binned-SAH
+ * binary tree of the scene by the shipped library's collapse rule (leaf slots of
+ * <= 3 triangles): the yardstick for ptc_scene_info::sah_cost. *n_wide_nodes
+ * (may be NULL) receives the number of wide nodes. */
+double pt_scene_wide_sah_cost(const pt_scene *scene, uint64_t *n_wide_nodes);
 
 /* --- intersection --------------------------------------------------------- */
 /* rays: n * 6 floats (origin, dir). use_bvh = 0 is the brute-force definition,

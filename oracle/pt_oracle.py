@@ -117,6 +117,8 @@ def lib():
         L.pt_scene_world_triangles.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_scene_bvh_sah_cost.restype = C.c_double
         L.pt_scene_bvh_sah_cost.argtypes = [C.c_void_p]
+        L.pt_scene_wide_sah_cost.restype = C.c_double
+        L.pt_scene_wide_sah_cost.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.pt_miss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.pt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
                                    C.c_int, C.c_void_p, C.c_void_p]
@@ -314,6 +316,13 @@ class Scene:
 
     def sah_cost(self) -> float:
         return lib().pt_scene_bvh_sah_cost(self.handle)
+
+    def wide_sah_cost(self):
+        """(cost, wide nodes) of the 8-wide collapse of a top-down binned-SAH tree of
+        this scene: the yardstick for the shipped library's ptc_scene_info.sah_cost."""
+        n = C.c_uint64(0)
+        cost = lib().pt_scene_wide_sah_cost(self.handle, C.byref(n))
+        return cost, n.value
 
     def miss(self, d):
         d = _f32(d)
