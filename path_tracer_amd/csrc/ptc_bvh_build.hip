@@ -1108,6 +1108,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
     scene->d.nodes = static_cast<const uint4 *>(scene->d_nodes);
     scene->d.tris = static_cast<const float4 *>(scene->d_tris);
     scene->info.n_nodes = n_nodes;
+    scene->d.n_nodes = n_nodes;
     scene->info.bvh_depth = depth;
     scene->info.build_ms = ms;
     scene->info.sah_cost = root_half_area > 0.0 ? (float)(1.0 + h_cost / root_half_area) : 1.0f;
@@ -1412,6 +1413,7 @@ int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &
     scene->d.tris = static_cast<const float4 *>(scene->d_tris);
     scene->d.inst_box = scene->d_inst_box;
     scene->info.n_nodes = total_nodes;
+    scene->d.n_nodes = total_nodes;
     scene->info.bvh_depth = depth;
     scene->info.build_ms = build_ms;
     scene->info.sah_cost = total_tris ? (float)(sah_weighted / total_tris) : 1.0f;

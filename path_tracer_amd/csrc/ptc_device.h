@@ -49,6 +49,7 @@ struct DScene
     uint32_t env_w, env_h;
     uint32_t n_instances;
     uint32_t n_tris;
+    uint32_t n_nodes; // entries of nodes
 };
 
 // Push_constants of src/renderer.cpp:27-42 plus the build's explicit knobs.

@@ -28,6 +28,7 @@
 #include "ptc_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 // Workspace of ptc_render_static(): callers that cannot allocate (code under
@@ -40,6 +41,9 @@
 // a GPU share it, so calls that overlap on one GPU race.
 constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+// Debugging aid: cycles the persistent kernel's waves spent in each part of their loop (PTC_DRAIN_PROFILE=1).
+static __device__ unsigned long long g_drain_prof[16];
 
 namespace ptc
 {
@@ -332,6 +336,27 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
 // of a mesh's tree carry no instance: a test that improved the hit marks it
 // with the instance the lane is in.
 template <bool kTwoLevel>
+PTC_DEV void drain_tri_eval(const float4 a, const float4 b, const float4 c, const RayCtx &R, uint32_t inst, Hit &best)
+{
+    if (!kTwoLevel)
+    {
+        tri_eval(a, b, c, R, best);
+        return;
+    }
+    const float t0 = best.t;
+    const uint32_t f0 = best.instance == inst ? best.flat : kNoHit;
+    Hit cand = best;
+    cand.flat = f0;
+    tri_eval(a, b, c, R, cand);
+    const bool improved = cand.t != t0 || cand.flat != f0;
+    best.t = improved ? cand.t : best.t;
+    best.u = improved ? cand.u : best.u;
+    best.v = improved ? cand.v : best.v;
+    best.flat = improved ? cand.flat : best.flat;
+    best.instance = improved ? inst : best.instance;
+}
+
+template <bool kTwoLevel>
 PTC_DEV void drain_tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index, uint32_t inst, Hit &best)
 {
     if (!kTwoLevel)
@@ -361,7 +386,20 @@ PTC_DEV void drain_tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index
 // atomic per wave), walks it bounce by bounce to its end, then pulls the next,
 // which keeps the lanes of a wave busy until the queue is empty. Every wave
 // leaves the loop once the queue is exhausted and its own lanes are done.
-constexpr int kDrainLds = 16; // LDS stack entries per lane in the drain kernel (two pushes per level)
+// Shape of the persistent kernel. 256 threads; 6 LDS stack entries per lane (two
+// pushes per level; deeper entries go to scratch: 8 entries are no faster, 4
+// cost 6 %); built for 5 resident waves per SIMD (96 registers). The kernel is
+// bound by memory latency that its resident waves have to cover: 2 / 3 / 4 / 5
+// waves per SIMD finish the 871k-triangle scene's 256-spp launch in 66.6 / 49.3
+// / 41.6 / 38.4 ms. Six need 80 registers, which the compiler only reaches by
+// spilling loop invariants to scratch (43.9 ms and worse).
+// (Camera items keep three more words per lane in LDS, which leaves room for 4.)
+constexpr int kDrainBlock = 256, kDrainLds = 6;
+constexpr int drain_waves(bool camera)
+{
+    return camera ? 4 : 5;
+}
+
 // kCamera = false: work items are the live paths of queue B.q[src] (n read from
 // B.counts[bounce0]). kCamera = true: work items are (pixel, dispatch) pairs,
 // n_items of them, generated in place as camera rays: item i covers lane
@@ -369,18 +407,30 @@ constexpr int kDrainLds = 16; // LDS stack entries per lane in the drain kernel 
 // a wave that pulls 64 items at once gets one coherent tile; the
 // samples_per_frame samples of an item run back to back in the same lane on
 // one RNG stream, as shader.rgen:179 does.
-template <bool kCamera, bool kTwoLevel>
-__global__ void __launch_bounds__(kBlock, 4)
+// kProfile: also sums, per wave, the cycles spent in each part of the loop
+// (g_drain_prof; a debugging aid that serialises the loop's memory waits).
+template <bool kCamera, bool kTwoLevel, bool kProfile>
+__global__ void __launch_bounds__(kDrainBlock, drain_waves(kCamera))
 k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t n_items, uint32_t n_disp,
            uint32_t k_first, uint32_t *__restrict__ head, DeviceStats *__restrict__ stats)
 {
-    __shared__ uint2 s_stack[kDrainLds * kBlock];
+    __shared__ uint2 s_stack[kDrainLds * kDrainBlock];
+    // What a path carries but only its shading needs (throughput, radiance, RNG
+    // state, path id, bounce number; for camera items also the pixel and the
+    // sample number) stays in LDS, one word per lane and field, and is in
+    // registers only inside the shading and pull phases. Ten more words per lane
+    // take the traversal state of the lanes that are not shaded during a shading
+    // phase, whose own register need is the kernel's largest. The traversal
+    // loop, whose register count sets the number of resident waves, then carries
+    // the ray, the hit and the traversal state only (119 -> 93 registers).
+    constexpr int kCold = kCamera ? 12 : 9, kParked = 10;
+    __shared__ uint32_t s_words[(kCold + kParked) * kDrainBlock];
+#define PTC_WORD(w) s_words[(w) * kDrainBlock + threadIdx.x]
     const WfState qi = B.q[src];
     const uint32_t max_depth = F.max_depth;
     const float tmax = F.tmax;
     const uint32_t n = kCamera ? n_items : B.counts[bounce0];
     const uint32_t lane = lane_id();
-    uint32_t px = 0, py = 0, sample = 0; // kCamera: the item's pixel and current sample
     // Lane state machine. A lane is idle (kIdle), walking the tree for its
     // path's current ray (kTrav), or has its closest hit and waits to be shaded
     // (kShade). Every loop iteration runs at most one node visit per lane, so
@@ -404,18 +454,71 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     uint32_t seg = blockIdx.x % kSegments, segs_left = kSegments;
     bool queue_done = n == 0u;                // nothing left to reserve beyond chunk_end
     bool exhausted = n == 0u;
-    PathState ps = camera_path(F, 0u, 0u, 0u);
-    uint32_t pid = 0, bounce = 0, rays = 0;
-    RayCtx R = make_ray_ctx(v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f), tmax);
+    // the lane's current ray in world space, and its per-ray traversal constants
+    vec3 org = v3(0.0f, 0.0f, 0.0f), dir = v3(0.0f, 0.0f, 1.0f);
+    float idx = 1.0f, idy = 1.0f, idz = 1.0f;
+    uint32_t octinv = 7u;
+    // Two-level scenes: the ray in the object space of the instance whose tree the
+    // lane is in (with its t limit there), that instance, and the lane's place in
+    // the instance tree; best.flat is then the primitive index within the mesh of
+    // best.instance. (Flattened scenes trace the world-space ray itself.)
+    vec3 obj_o = org, obj_d = dir;
+    float obj_tmax = tmax;
+    uint32_t inst = 0u, inst_pos = 0u;
+    auto ray_ctx = [&]() {
+        RayCtx R;
+        R.o = kTwoLevel ? obj_o : org;
+        R.d = kTwoLevel ? obj_d : dir;
+        R.idx = idx;
+        R.idy = idy;
+        R.idz = idz;
+        R.octinv = octinv;
+        R.tmax = kTwoLevel ? obj_tmax : tmax;
+        return R;
+    };
+    auto set_ray = [&](vec3 o, vec3 d, float limit) {
+        const RayCtx R = make_ray_ctx(o, d, limit);
+        idx = R.idx;
+        idy = R.idy;
+        idz = R.idz;
+        octinv = R.octinv;
+        if (kTwoLevel)
+        {
+            obj_o = o;
+            obj_d = d;
+            obj_tmax = limit;
+        }
+    };
+    auto store_cold = [&](const PathState &ps, uint32_t pid, uint32_t bounce) {
+        PTC_WORD(0) = __float_as_uint(ps.throughput.x);
+        PTC_WORD(1) = __float_as_uint(ps.throughput.y);
+        PTC_WORD(2) = __float_as_uint(ps.throughput.z);
+        PTC_WORD(3) = __float_as_uint(ps.radiance.x);
+        PTC_WORD(4) = __float_as_uint(ps.radiance.y);
+        PTC_WORD(5) = __float_as_uint(ps.radiance.z);
+        PTC_WORD(6) = ps.rng;
+        PTC_WORD(7) = pid;
+        PTC_WORD(8) = bounce;
+    };
+    uint32_t wave_rays = 0u; // rays started by this wave (wave-uniform)
     Hit best = no_hit(tmax);
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
     uint2 *const lds = s_stack + threadIdx.x;
     uint2 spill[kStackTotal - kDrainLds];
     int sp = 0;
-    // Two-level scenes: the instance whose tree the lane is in and the lane's
-    // place in the instance tree. R is then the ray in that instance's object
-    // space, best.flat the primitive index within the mesh of best.instance.
-    uint32_t inst = 0u, inst_pos = 0u;
+    // kProfile: cycles per loop part (0 loop top, 1 shading, 2 pull, 3 ray start
+    // and stack pop, 4 node visit, 5 triangle tests, 6 further triangle rounds),
+    // then 7 further rounds run, 8 shading phases, 9 iterations
+    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
+#define PTC_PROF(k)                                                     \
+    if (kProfile)                                                       \
+    {                                                                   \
+        __builtin_amdgcn_s_waitcnt(0);                                  \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();  \
+        prof[k] += t_now - t_prev;                                      \
+        t_prev = t_now;                                                 \
+    }
     for (;;)
     {
         const unsigned long long trav = __ballot(mode == kTrav);
@@ -424,8 +527,22 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
         const unsigned long long shade = __ballot(mode == kShade);
         const uint32_t n_shade = (uint32_t)__builtin_popcountll(shade);
         const bool run_shade = n_shade != 0u && (n_shade >= kShadeMin || trav == 0ull);
+        PTC_PROF(0)
         if (run_shade)
         {
+            // park what the lanes that are not shaded still need (the compiler
+            // barriers keep it from holding the values in registers all the same)
+            PTC_WORD(kCold + 0) = __float_as_uint(idx);
+            PTC_WORD(kCold + 1) = __float_as_uint(idy);
+            PTC_WORD(kCold + 2) = __float_as_uint(idz);
+            PTC_WORD(kCold + 3) = octinv;
+            PTC_WORD(kCold + 4) = ng.x;
+            PTC_WORD(kCold + 5) = ng.y;
+            PTC_WORD(kCold + 6) = tg.x;
+            PTC_WORD(kCold + 7) = tg.y;
+            PTC_WORD(kCold + 8) = (uint32_t)sp;
+            PTC_WORD(kCold + 9) = __float_as_uint(best.t);
+            __asm__ volatile("" ::: "memory");
             if (mode == kShade)
             {
                 if (kTwoLevel && best.flat != kNoHit)
@@ -433,6 +550,14 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                     best.primitive = best.flat;
                     best.flat += S.instances[best.instance].first_flat;
                 }
+                PathState ps;
+                ps.origin = org;
+                ps.dir = dir;
+                ps.throughput = v3(__uint_as_float(PTC_WORD(0)), __uint_as_float(PTC_WORD(1)), __uint_as_float(PTC_WORD(2)));
+                ps.radiance = v3(__uint_as_float(PTC_WORD(3)), __uint_as_float(PTC_WORD(4)), __uint_as_float(PTC_WORD(5)));
+                ps.rng = PTC_WORD(6);
+                uint32_t pid = PTC_WORD(7);
+                uint32_t bounce = PTC_WORD(8);
                 const bool alive = path_bounce(S, best, ps) && (bounce + 1u) < max_depth;
                 ++bounce;
                 if (alive)
@@ -442,13 +567,15 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 else if (kCamera)
                 {
                     B.radiance[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, 1.0f);
-                    if (++sample < B.spf)
+                    const uint32_t sample = PTC_WORD(11) + 1u;
+                    if (sample < B.spf)
                     {
                         // next sample of the same dispatch continues the RNG stream
                         pid += B.n_pixels;
-                        ps = camera_path(F, px, py, ps.rng);
+                        ps = camera_path(F, PTC_WORD(9), PTC_WORD(10), ps.rng);
                         bounce = 0u;
                         start = true;
+                        PTC_WORD(11) = sample;
                     }
                     else
                     {
@@ -460,8 +587,27 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                     finish_path(B, pid, ps.radiance, ps.rng);
                     mode = kIdle;
                 }
+                org = ps.origin;
+                dir = ps.dir;
+                store_cold(ps, pid, bounce);
+            }
+            __asm__ volatile("" ::: "memory");
+            idx = __uint_as_float(PTC_WORD(kCold + 0));
+            idy = __uint_as_float(PTC_WORD(kCold + 1));
+            idz = __uint_as_float(PTC_WORD(kCold + 2));
+            octinv = PTC_WORD(kCold + 3);
+            ng.x = PTC_WORD(kCold + 4);
+            ng.y = PTC_WORD(kCold + 5);
+            tg.x = PTC_WORD(kCold + 6);
+            tg.y = PTC_WORD(kCold + 7);
+            sp = (int)PTC_WORD(kCold + 8);
+            best.t = __uint_as_float(PTC_WORD(kCold + 9));
+            if (kProfile)
+            {
+                prof[8] += 1;
             }
         }
+        PTC_PROF(1)
         // ---- pull new paths for idle lanes: when enough are idle, and right
         // after a shading phase (the lanes whose paths just ended restart together
         // with the lanes whose paths continue, instead of waiting for company)
@@ -507,27 +653,35 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 const uint32_t tile_k = i >> 6, l = i & 63u;
                 const uint32_t tile = tile_k / n_disp, k = tile_k % n_disp;
                 const uint32_t tiles_x = (F.width + 7u) >> 3;
-                px = (tile % tiles_x) * 8u + (l & 7u);
-                py = (tile / tiles_x) * 8u + (l >> 3);
+                const uint32_t px = (tile % tiles_x) * 8u + (l & 7u);
+                const uint32_t py = (tile / tiles_x) * 8u + (l >> 3);
                 got = px < F.width && py < F.height;
                 if (got)
                 {
                     const uint32_t pixel_index = py * F.width + px;
-                    sample = 0u;
-                    pid = path_id(B, pixel_index, k, 0u);
-                    ps = camera_path(F, px, py,
-                                     seed_(pixel_index, F.global_frame_count + (k_first + k) * F.frame_stride));
-                    bounce = 0u;
+                    const PathState ps = camera_path(F, px, py, seed_(pixel_index, F.global_frame_count +
+                                                                                       (k_first + k) * F.frame_stride));
+                    org = ps.origin;
+                    dir = ps.dir;
+                    store_cold(ps, path_id(B, pixel_index, k, 0u), 0u);
+                    PTC_WORD(9) = px;
+                    PTC_WORD(10) = py;
+                    PTC_WORD(11) = 0u;
                 }
             }
             else if (got)
             {
-                pid = load_state(qi, i, ps);
-                bounce = bounce0;
+                PathState ps;
+                const uint32_t pid = load_state(qi, i, ps);
+                org = ps.origin;
+                dir = ps.dir;
+                store_cold(ps, pid, bounce0);
             }
             start = start || got;
             exhausted = queue_done && chunk_next == chunk_end; // wave-uniform
         }
+        PTC_PROF(2)
+        wave_rays += (uint32_t)__builtin_popcountll(__ballot(start));
         if (start)
         {
             best = no_hit(tmax);
@@ -538,13 +692,12 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             }
             else
             {
-                R = make_ray_ctx(ps.origin, ps.dir, tmax);
+                set_ray(org, dir, tmax);
                 ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
             }
             tg = make_uint2(0u, 0u);
             sp = 0;
             mode = kTrav;
-            ++rays;
         }
         if (exhausted && __ballot(mode != kIdle) == 0ull)
         {
@@ -559,13 +712,12 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 if (kTwoLevel)
                 {
                     // on to the next instance whose world box the ray meets
-                    const uint32_t next = next_instance(S, inst_pos, ps.origin, ps.dir, best.t);
+                    const uint32_t next = next_instance(S, inst_pos, org, dir, best.t);
                     if (next != kNoInstance)
                     {
                         inst = next;
                         const DInstance *__restrict__ I = &S.instances[inst];
-                        R = make_ray_ctx(xform_point(I->w2o, ps.origin), xform_vector(I->w2o, ps.dir),
-                                         instance_t_limit(best, inst));
+                        set_ray(xform_point(I->w2o, org), xform_vector(I->w2o, dir), instance_t_limit(best, inst));
                         ng = make_uint2(I->blas_root, 0x80000000u);
                         mode = kTrav;
                     }
@@ -573,7 +725,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             }
             else
             {
-                const uint2 e = stack_pop<kDrainLds>(lds, kBlock, spill, sp);
+                const uint2 e = stack_pop<kDrainLds>(lds, kDrainBlock, spill, sp);
                 if (e.y & kNodeBits)
                 {
                     ng = e;
@@ -584,32 +736,63 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 }
             }
         }
+        PTC_PROF(3)
         // ---- one node visit for every lane that has one pending
         if (mode == kTrav && (ng.y & kNodeBits))
         {
-            const uint32_t node_idx = next_child(ng, R.octinv);
+            const uint32_t node_idx = next_child(ng, octinv);
             if (ng.y & kNodeBits)
             {
-                stack_push<kDrainLds>(lds, kBlock, spill, sp, ng);
+                stack_push<kDrainLds>(lds, kDrainBlock, spill, sp, ng);
             }
             if (tg.y)
             {
-                stack_push<kDrainLds>(lds, kBlock, spill, sp, tg); // triangles found earlier and not tested yet
+                stack_push<kDrainLds>(lds, kDrainBlock, spill, sp, tg); // triangles found earlier and not tested yet
             }
-            node_test<kCamera>(S, R, best.t, node_idx, ng, tg);
+            node_test<kCamera>(S, ray_ctx(), best.t, node_idx, ng, tg);
         }
-        // ---- at most one triangle test per lane and iteration, so that lanes with
-        // many pending triangles do not hold the wave
-        if (mode == kTrav && tg.y != 0u)
+        PTC_PROF(4)
+        // ---- one triangle test per lane and iteration, so that lanes with many
+        // pending triangles do not hold the wave; two when enough lanes of the wave
+        // have a second one pending (leaf slots hold up to three), with both
+        // records requested before either is tested: one memory round trip.
         {
-            const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
-            tg.y &= tg.y - 1u;
-            drain_tri_test<kTwoLevel>(S, R, tg.x + i, inst, best);
+            const bool t1 = mode == kTrav && tg.y != 0u;
+            const uint32_t i1 = (uint32_t)__builtin_ctz(tg.y | 0x80000000u);
+            const uint32_t rest = tg.y & (tg.y - 1u);
+            const bool t2 = t1 && rest != 0u &&
+                            (uint32_t)__builtin_popcountll(__ballot(t1 && rest != 0u)) >= kTriMoreMin;
+            const uint32_t i2 = (uint32_t)__builtin_ctz(rest | 0x80000000u);
+            float4 a1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b1 = a1, c1 = a1, a2 = a1, b2 = a1, c2 = a1;
+            if (t1)
+            {
+                const float4 *__restrict__ T = S.tris + 3u * (size_t)(tg.x + i1);
+                a1 = T[0];
+                b1 = T[1];
+                c1 = T[2];
+            }
+            if (t2)
+            {
+                const float4 *__restrict__ T = S.tris + 3u * (size_t)(tg.x + i2);
+                a2 = T[0];
+                b2 = T[1];
+                c2 = T[2];
+            }
+            if (t1)
+            {
+                drain_tri_eval<kTwoLevel>(a1, b1, c1, ray_ctx(), inst, best);
+                tg.y = rest;
+            }
+            if (t2)
+            {
+                drain_tri_eval<kTwoLevel>(a2, b2, c2, ray_ctx(), inst, best);
+                tg.y = rest & (rest - 1u);
+            }
         }
+        PTC_PROF(5)
         // While many lanes of the wave still have triangles pending (scenes with
-        // few, large leaves are bound by this), they test up to three more right
-        // away (more than three gains nothing).
-        for (int extra = 0; extra < 3; ++extra)
+        // few, large leaves are bound by this), they test up to two more right away.
+        for (int extra = 0; extra < 2; ++extra)
         {
             const bool more = mode == kTrav && tg.y != 0u;
             if ((uint32_t)__builtin_popcountll(__ballot(more)) < kTriMoreMin)
@@ -620,18 +803,31 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             {
                 const uint32_t i = (uint32_t)__builtin_ctz(tg.y);
                 tg.y &= tg.y - 1u;
-                drain_tri_test<kTwoLevel>(S, R, tg.x + i, inst, best);
+                drain_tri_test<kTwoLevel>(S, ray_ctx(), tg.x + i, inst, best);
+            }
+            if (kProfile)
+            {
+                prof[7] += 1;
             }
         }
+        PTC_PROF(6)
+        if (kProfile)
+        {
+            prof[9] += 1;
+        }
     }
-    unsigned long long wr = rays;
-    for (int off = 32; off > 0; off >>= 1)
+#undef PTC_PROF
+#undef PTC_WORD
+    if (kProfile && lane == 0u)
     {
-        wr += __shfl_xor(wr, off, 64);
+        for (int k = 0; k < 10; ++k)
+        {
+            atomicAdd(&g_drain_prof[k], prof[k]);
+        }
     }
-    if (lane == 0u && wr != 0ull)
+    if (lane == 0u && wave_rays != 0u)
     {
-        atomicAdd(&stats->rays, wr);
+        atomicAdd(&stats->rays, (unsigned long long)wave_rays);
     }
 }
 
@@ -696,6 +892,32 @@ __global__ void k_wf_stats(const uint32_t *__restrict__ counts, uint32_t n_paths
 size_t align256(size_t x)
 {
     return (x + 255) & ~(size_t)255;
+}
+
+// Launches the persistent kernel over at most max_items work items: as many
+// blocks as the chip holds at the kernel's waves per SIMD.
+template <bool kCamera>
+void launch_drain(ptc_context *ctx, const ptc_scene *scene, const DFrame &F0, const WfBuffers &B, uint32_t bounce0,
+                  int src, uint32_t n_items, uint32_t n_disp, uint32_t k_first, uint32_t max_items)
+{
+    const bool two_level = scene->d.inst_box != nullptr;
+    uint32_t *heads = B.counts + (F0.max_depth + 1u);
+    const uint32_t resident = (uint32_t)ctx->n_cus * (4u * (uint32_t)drain_waves(kCamera) * 64u / (uint32_t)kDrainBlock);
+    const uint32_t blocks = std::max(1u, std::min(resident, (max_items + kDrainBlock - 1u) / kDrainBlock));
+    auto go = [&](auto kernel) {
+        kernel<<<blocks, kDrainBlock, 0, ctx->stream>>>(scene->d, F0, B, bounce0, src, n_items, n_disp, k_first, heads,
+                                                        ctx->d_stats);
+    };
+    // PTC_DRAIN_PROFILE=1 (debugging): the variant that times its loop parts, read by ptc_debug_drain_profile()
+    static const bool profile = getenv("PTC_DRAIN_PROFILE") != nullptr && atoi(getenv("PTC_DRAIN_PROFILE")) != 0;
+    if (profile)
+    {
+        two_level ? go(k_wf_drain<kCamera, true, true>) : go(k_wf_drain<kCamera, false, true>);
+    }
+    else
+    {
+        two_level ? go(k_wf_drain<kCamera, true, false>) : go(k_wf_drain<kCamera, false, false>);
+    }
 }
 
 // Workspace bytes of a batch of max_batch dispatches (the carving order of
@@ -837,17 +1059,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             PTC_HIP_CHECK(hipMemsetAsync(B.counts, 0, n_counts * 4, st));
             {
                 PhaseTimer timer(ctx, PTC_PHASE_DRAIN);
-                const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_items + kBlock - 1) / kBlock);
-                if (two_level)
-                {
-                    k_wf_drain<true, true><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, 0u, 0, n_items, nb, k0,
-                                                                     B.counts + (F0.max_depth + 1u), ctx->d_stats);
-                }
-                else
-                {
-                    k_wf_drain<true, false><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, 0u, 0, n_items, nb, k0,
-                                                                      B.counts + (F0.max_depth + 1u), ctx->d_stats);
-                }
+                launch_drain<true>(ctx, scene, F0, B, 0u, 0, n_items, nb, k0, n_items);
             }
             k_wf_stats<<<1, 64, 0, st>>>(B.counts, n_paths * spf, 0u, 1u, ctx->d_stats);
         }
@@ -918,18 +1130,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             if (drain_b < F0.max_depth)
             {
                 PhaseTimer timer(ctx, PTC_PHASE_DRAIN);
-                if (two_level)
-                {
-                    k_wf_drain<false, true><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, drain_b, (int)(drain_b & 1u), 0u,
-                                                                      0u, 0u, B.counts + (F0.max_depth + 1u),
-                                                                      ctx->d_stats);
-                }
-                else
-                {
-                    k_wf_drain<false, false><<<blocks, kBlock, 0, st>>>(scene->d, F0, B, drain_b, (int)(drain_b & 1u), 0u,
-                                                                       0u, 0u, B.counts + (F0.max_depth + 1u),
-                                                                       ctx->d_stats);
-                }
+                launch_drain<false>(ctx, scene, F0, B, drain_b, (int)(drain_b & 1u), 0u, 0u, 0u, n_paths);
             }
             k_wf_stats<<<1, 64, 0, st>>>(B.counts, n_paths, F0.max_depth, drain_b, ctx->d_stats);
         }
@@ -945,3 +1146,15 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
 }
 
 } // namespace ptc
+
+// Debugging aid (not part of the public header): reads and clears the cycle
+// counters of the profiled persistent kernel (tools/drain_prof.py).
+extern "C" int ptc_debug_drain_profile(unsigned long long *out16)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_drain_prof), sizeof(unsigned long long) * 16) != hipSuccess)
+    {
+        return -1;
+    }
+    unsigned long long zero[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_drain_prof), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
