@@ -302,6 +302,30 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
 int ptc_render_static(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
                       const ptc_camera *camera, const ptc_render_params *params);
 
+/* draw_frame() as the reference issues it: the call records its commands and
+ * returns while earlier frames still run (frames_in_flight, src/renderer.hpp:208;
+ * the queue submit of src/renderer.cpp:2170-2172 does not wait). Same arguments
+ * and same film, bit for bit, as ptc_render(); the dispatch is recorded on the
+ * film, not launched. A call that continues the recorded run (same scene,
+ * camera bytes and parameters, global_frame_count = the run's next frame count)
+ * extends it; anything else launches the run first, as one ptc_render() of all
+ * its dispatches, so a loop of one-dispatch calls reaches the rate of a batched
+ * call. The run is also launched once it holds max_paths_in_flight paths, by
+ * ptc_film_flush(), ptc_synchronize() and ptc_get_stats() / ptc_render_times() /
+ * ptc_phase_times(), before the scene is destroyed, and by everything that
+ * reads or writes the film (read-backs, ptc_write_png, ptc_film_resolve,
+ * ptc_render*, ptc_film_set_sample_count to another count); ptc_film_reset()
+ * and ptc_film_destroy() drop it. ptc_film_sample_count() includes the
+ * recorded samples. Not covered: a device pointer taken with
+ * ptc_film_accum_device_ptr() or handed to ptc_film_create() is only current
+ * after ptc_film_flush(). An error of a deferred launch is returned by the call
+ * that launches it. The camera and the parameters are copied; the scene must
+ * stay alive (ptc_scene_destroy() launches what uses it). */
+int ptc_render_deferred(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
+                        const ptc_camera *camera, const ptc_render_params *params);
+/* Launches the dispatches recorded on the film, if any (asynchronous). */
+int ptc_film_flush(ptc_film *film);
+
 /* Flattened triangle index hit by the first sample's camera ray of every
  * pixel for one dispatch (the hit the reference would report through
  * gl_InstanceID / gl_PrimitiveID at bounce 0). ids_out: w*h host uint32. */

@@ -205,6 +205,47 @@ bool write_png_rgba8(const char *file_name, const uint8_t *rgba, uint32_t w, uin
 
 using namespace ptc;
 
+namespace
+{
+int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const ptc_camera *camera,
+                const ptc_render_params *params, bool static_scratch);
+
+// Launches the dispatches a film has recorded (ptc_render_deferred) as one
+// ptc_render; nothing to do when there are none.
+int flush_film(ptc_film *film)
+{
+    if (film->pending.params.n_frames == 0u)
+    {
+        return PTC_OK;
+    }
+    const ptc_film::Pending job = film->pending;
+    film->pending.params.n_frames = 0u;
+    film->pending.scene = nullptr;
+    return render_impl(film->ctx, job.scene, film, &job.camera, &job.params, false);
+}
+
+// Every film of the context; with a scene given, only the films whose recorded
+// dispatches use it.
+int flush_context(ptc_context *ctx, const ptc_scene *only_scene = nullptr)
+{
+    int rc = PTC_OK;
+    for (ptc_film *film : ctx->films)
+    {
+        if (only_scene == nullptr || film->pending.scene == only_scene)
+        {
+            const int r = flush_film(film);
+            rc = rc == PTC_OK ? r : rc;
+        }
+    }
+    return rc;
+}
+
+uint32_t pending_samples(const ptc_film *film)
+{
+    return film->pending.params.n_frames * film->pending.params.samples_per_frame;
+}
+} // namespace
+
 extern "C" {
 
 const char *ptc_last_error(void)
@@ -335,6 +376,11 @@ int ptc_synchronize(ptc_context *ctx)
     if (use_device(ctx) != PTC_OK)
     {
         return PTC_E_DEVICE;
+    }
+    const int rc = flush_context(ctx);
+    if (rc != PTC_OK)
+    {
+        return rc;
     }
     PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return PTC_OK;
@@ -555,6 +601,7 @@ void ptc_scene_destroy(ptc_scene *scene)
         return;
     }
     (void)hipSetDevice(scene->ctx->device);
+    (void)flush_context(scene->ctx, scene); // recorded dispatches that use this scene run first
     (void)hipStreamSynchronize(scene->ctx->stream);
     (void)hipFree(scene->d_nodes);
     (void)hipFree(scene->d_tris);
@@ -659,6 +706,7 @@ int ptc_film_create(ptc_context *ctx, uint32_t width, uint32_t height, void *acc
         F->own_rgba8 = true;
         (void)hipMemsetAsync(F->d_rgba8, 0, n * 4, ctx->stream);
     }
+    ctx->films.push_back(F);
     *out = F;
     return PTC_OK;
 }
@@ -671,6 +719,9 @@ void ptc_film_destroy(ptc_film *film)
     }
     (void)hipSetDevice(film->ctx->device);
     (void)hipStreamSynchronize(film->ctx->stream);
+    // (dispatches recorded and not launched are dropped with the film)
+    auto &films = film->ctx->films;
+    films.erase(std::remove(films.begin(), films.end(), film), films.end());
     if (film->own_accum)
     {
         (void)hipFree(film->d_accum);
@@ -689,13 +740,16 @@ int ptc_film_reset(ptc_film *film)
         set_error("ptc_film_reset: film is NULL");
         return PTC_E_INVALID;
     }
+    // the next dispatch overwrites the film, so dispatches recorded and not yet launched need not run
+    film->pending.params.n_frames = 0u;
+    film->pending.scene = nullptr;
     film->sample_count = 0;
     return PTC_OK;
 }
 
 uint32_t ptc_film_sample_count(const ptc_film *film)
 {
-    return film ? film->sample_count : 0u;
+    return film ? film->sample_count + pending_samples(film) : 0u;
 }
 
 int ptc_film_set_sample_count(ptc_film *film, uint32_t sample_count)
@@ -705,8 +759,13 @@ int ptc_film_set_sample_count(ptc_film *film, uint32_t sample_count)
         set_error("ptc_film_set_sample_count: film is NULL");
         return PTC_E_INVALID;
     }
+    if (sample_count == film->sample_count + pending_samples(film))
+    {
+        return PTC_OK; // already there, recorded dispatches included
+    }
+    const int rc = flush_film(film);
     film->sample_count = sample_count;
-    return PTC_OK;
+    return rc;
 }
 
 int ptc_film_read_accum(ptc_film *film, float *rgba_out)
@@ -719,6 +778,10 @@ int ptc_film_read_accum(ptc_film *film, float *rgba_out)
     if (use_device(film->ctx) != PTC_OK)
     {
         return PTC_E_DEVICE;
+    }
+    if (const int rc = flush_film(film); rc != PTC_OK)
+    {
+        return rc;
     }
     const size_t n = (size_t)film->width * film->height;
     PTC_HIP_CHECK(hipMemcpyAsync(rgba_out, film->d_accum, n * 16, hipMemcpyDeviceToHost, film->ctx->stream));
@@ -736,6 +799,10 @@ int ptc_film_read_rgba8(ptc_film *film, uint8_t *rgba_out)
     if (use_device(film->ctx) != PTC_OK)
     {
         return PTC_E_DEVICE;
+    }
+    if (const int rc = flush_film(film); rc != PTC_OK)
+    {
+        return rc;
     }
     const size_t n = (size_t)film->width * film->height;
     PTC_HIP_CHECK(hipMemcpyAsync(rgba_out, film->d_rgba8, n * 4, hipMemcpyDeviceToHost, film->ctx->stream));
@@ -758,6 +825,10 @@ int ptc_film_resolve(ptc_film *film, int sum_mode)
     if (use_device(film->ctx) != PTC_OK)
     {
         return PTC_E_DEVICE;
+    }
+    if (const int rc = flush_film(film); rc != PTC_OK)
+    {
+        return rc;
     }
     return launch_resolve(film->ctx, film, sum_mode);
 }
@@ -793,7 +864,7 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
         return PTC_E_INVALID;
     }
     const uint64_t added = (uint64_t)params->samples_per_frame * params->n_frames;
-    if ((uint64_t)film->sample_count + added > 0xffffffffull)
+    if ((uint64_t)film->sample_count + pending_samples(film) + added > 0xffffffffull)
     {
         set_error("ptc_render: sample count overflow");
         return PTC_E_LIMIT;
@@ -801,6 +872,11 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
     if (use_device(ctx) != PTC_OK)
     {
         return PTC_E_DEVICE;
+    }
+    // dispatches recorded on this film come first (never the case when this is the flush itself)
+    if (const int rc = flush_film(film); rc != PTC_OK)
+    {
+        return rc;
     }
     DFrame F = make_frame(*camera, film->width, film->height);
     F.global_frame_count = params->global_frame_count;
@@ -886,6 +962,93 @@ int ptc_render_static(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, 
                       const ptc_render_params *params)
 {
     return render_impl(ctx, scene, film, camera, params, true);
+}
+
+int ptc_render_deferred(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const ptc_camera *camera,
+                        const ptc_render_params *params)
+{
+    if (!ctx || !scene || !film || !camera || !params)
+    {
+        set_error("ptc_render_deferred: NULL argument");
+        return PTC_E_INVALID;
+    }
+    if (scene->ctx != ctx || film->ctx != ctx)
+    {
+        set_error("ptc_render_deferred: scene or film belongs to another context");
+        return PTC_E_INVALID;
+    }
+    if (params->samples_per_frame == 0 || params->n_frames == 0)
+    {
+        set_error("ptc_render_deferred: samples_per_frame and n_frames must be >= 1");
+        return PTC_E_INVALID;
+    }
+    if (params->integrator > PTC_INTEGRATOR_AUTO || params->accumulate > PTC_ACCUM_SUM ||
+        params->tonemap > PTC_TONEMAP_ACES)
+    {
+        set_error("ptc_render_deferred: unknown integrator, accumulation mode or tonemap");
+        return PTC_E_INVALID;
+    }
+    const uint64_t added = (uint64_t)params->samples_per_frame * params->n_frames;
+    if ((uint64_t)film->sample_count + pending_samples(film) + added > 0xffffffffull)
+    {
+        set_error("ptc_render_deferred: sample count overflow");
+        return PTC_E_LIMIT;
+    }
+    ptc_render_params want = *params;
+    want.frame_stride = want.frame_stride ? want.frame_stride : 1u;
+    ptc_film::Pending &pend = film->pending;
+    // A call continues the recorded run when it differs from it in nothing but
+    // the frame count, and that is the run's next one.
+    bool continues = pend.params.n_frames != 0u && pend.scene == scene &&
+                     std::memcmp(&pend.camera, camera, sizeof(ptc_camera)) == 0;
+    if (continues)
+    {
+        ptc_render_params a = pend.params, b = want;
+        const uint32_t next = a.global_frame_count + a.n_frames * a.frame_stride;
+        continues = b.global_frame_count == next;
+        a.global_frame_count = b.global_frame_count = 0u;
+        a.n_frames = b.n_frames = 0u;
+        continues = continues && std::memcmp(&a, &b, sizeof a) == 0 &&
+                    (uint64_t)pend.params.n_frames + want.n_frames <= 0xffffffffull;
+    }
+    if (continues)
+    {
+        pend.params.n_frames += want.n_frames;
+    }
+    else
+    {
+        if (const int rc = flush_film(film); rc != PTC_OK)
+        {
+            return rc;
+        }
+        pend.scene = scene;
+        pend.camera = *camera;
+        pend.params = want;
+    }
+    // as many dispatches as one batch of the queue-based integrators holds
+    // (max_paths_in_flight); more would only wait for the next batch
+    const uint64_t per_dispatch = (uint64_t)film->width * film->height * want.samples_per_frame;
+    const uint64_t budget = want.max_paths_in_flight ? want.max_paths_in_flight : (1u << 27);
+    const uint64_t bound = std::max<uint64_t>(budget / std::max<uint64_t>(per_dispatch, 1u), 1u);
+    if (pend.params.n_frames >= bound)
+    {
+        return flush_film(film);
+    }
+    return PTC_OK;
+}
+
+int ptc_film_flush(ptc_film *film)
+{
+    if (!film)
+    {
+        set_error("ptc_film_flush: film is NULL");
+        return PTC_E_INVALID;
+    }
+    if (use_device(film->ctx) != PTC_OK)
+    {
+        return PTC_E_DEVICE;
+    }
+    return flush_film(film);
 }
 
 int ptc_primary_hits(ptc_context *ctx, const ptc_scene *scene, const ptc_camera *camera,
@@ -1025,6 +1188,10 @@ int ptc_get_stats(ptc_context *ctx, ptc_stats *out)
     {
         return PTC_E_DEVICE;
     }
+    if (const int rc = flush_context(ctx); rc != PTC_OK)
+    {
+        return rc;
+    }
     DeviceStats s{};
     PTC_HIP_CHECK(hipMemcpyAsync(&s, ctx->d_stats, sizeof s, hipMemcpyDeviceToHost, ctx->stream));
     PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1058,6 +1225,10 @@ int ptc_render_times(ptc_context *ctx, double *ms_out, size_t capacity, size_t *
     {
         return PTC_E_DEVICE;
     }
+    if (const int rc = flush_context(ctx); rc != PTC_OK)
+    {
+        return rc;
+    }
     PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     size_t n = 0;
     for (size_t i = 0; i < ctx->ev_used && n < capacity; ++i)
@@ -1085,6 +1256,10 @@ int ptc_phase_times(ptc_context *ctx, double *ms_out, uint32_t *launches_out)
     if (use_device(ctx) != PTC_OK)
     {
         return PTC_E_DEVICE;
+    }
+    if (const int rc = flush_context(ctx); rc != PTC_OK)
+    {
+        return rc;
     }
     PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (uint32_t k = 0; k < PTC_N_PHASES; ++k)
@@ -1117,6 +1292,10 @@ int ptc_reset_stats(ptc_context *ctx)
     if (use_device(ctx) != PTC_OK)
     {
         return PTC_E_DEVICE;
+    }
+    if (const int rc = flush_context(ctx); rc != PTC_OK)
+    {
+        return rc;
     }
     PTC_HIP_CHECK(hipMemsetAsync(ctx->d_stats, 0, sizeof(DeviceStats), ctx->stream));
     return PTC_OK;

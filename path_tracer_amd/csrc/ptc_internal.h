@@ -39,6 +39,8 @@ struct DeviceStats
 
 } // namespace ptc
 
+struct ptc_film;
+
 struct ptc_context
 {
     int device = 0;
@@ -65,6 +67,7 @@ struct ptc_context
     void *static_scratch = nullptr;
     size_t static_scratch_bytes = 0;
     bool no_events = false; // set for the duration of a call that must not create events
+    std::vector<ptc_film *> films; // films created on this context (they may hold recorded dispatches)
 };
 
 struct ptc_scene
@@ -91,6 +94,15 @@ struct ptc_film
     uint32_t *d_rgba8 = nullptr;
     bool own_accum = false, own_rgba8 = false;
     uint32_t sample_count = 0;
+    // Dispatches recorded by ptc_render_deferred() and not launched yet
+    // (params.n_frames of them; 0 = none): consecutive calls with one scene, one
+    // camera and one parameter set collapse into one ptc_render().
+    struct Pending
+    {
+        const ptc_scene *scene = nullptr;
+        ptc_camera camera{};
+        ptc_render_params params{};
+    } pending;
 };
 
 namespace ptc

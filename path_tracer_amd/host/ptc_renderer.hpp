@@ -236,7 +236,12 @@ struct Image_f32
     return rr;
 }
 
-// The traced part of draw_frame (src/renderer.cpp:2015-2130, :2224).
+// The traced part of draw_frame (src/renderer.cpp:2015-2130, :2224). Like the
+// reference's, which submits its command buffer and returns with up to
+// frames_in_flight frames outstanding (src/renderer.hpp:208,
+// src/renderer.cpp:2170-2172), the call returns once its dispatch is recorded:
+// consecutive calls with one camera are launched together (ptc_render_deferred),
+// at the latest when something reads the film (write_to_png, a read-back).
 inline void draw_frame(Render_context &context, Render_resources &rr, const Camera &camera)
 {
     if (rr.sample_count == 0)
@@ -256,7 +261,7 @@ inline void draw_frame(Render_context &context, Render_resources &rr, const Came
         p.tonemap = rr.tonemap;
         p.accumulate = PTC_ACCUM_RUNNING_MEAN;
         detail::check(ptc_film_set_sample_count(rr.film, rr.sample_count), "draw_frame");
-        detail::check(ptc_render(context.handle, rr.scene, rr.film, &camera, &p), "draw_frame");
+        detail::check(ptc_render_deferred(context.handle, rr.scene, rr.film, &camera, &p), "draw_frame");
         rr.sample_count += samples_this_frame;
     }
     ++context.global_frame_count;

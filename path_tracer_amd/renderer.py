@@ -121,7 +121,8 @@ EXPORTS = [
     "ptc_scene_create", "ptc_scene_destroy", "ptc_scene_get_info", "ptc_scene_read_bvh",
     "ptc_film_create", "ptc_film_destroy", "ptc_film_reset", "ptc_film_sample_count",
     "ptc_film_set_sample_count", "ptc_film_read_accum", "ptc_film_read_rgba8",
-    "ptc_film_accum_device_ptr", "ptc_film_resolve", "ptc_render", "ptc_render_static", "ptc_primary_hits",
+    "ptc_film_accum_device_ptr", "ptc_film_resolve", "ptc_render", "ptc_render_static", "ptc_render_deferred", "ptc_film_flush",
+    "ptc_primary_hits",
     "ptc_trace_rays", "ptc_trace_rays_device", "ptc_get_stats", "ptc_render_times",
     "ptc_phase_times",
     "ptc_reset_stats",
@@ -164,6 +165,8 @@ def lib():
         L.ptc_film_resolve.argtypes = [vp, C.c_int]
         L.ptc_render.argtypes = [vp, vp, vp, C.POINTER(Camera), C.POINTER(RenderParams)]
         L.ptc_render_static.argtypes = [vp, vp, vp, C.POINTER(Camera), C.POINTER(RenderParams)]
+        L.ptc_render_deferred.argtypes = [vp, vp, vp, C.POINTER(Camera), C.POINTER(RenderParams)]
+        L.ptc_film_flush.argtypes = [vp]
         L.ptc_primary_hits.argtypes = [vp, vp, C.POINTER(Camera), u32, u32, u32, f32, vp]
         L.ptc_trace_rays.argtypes = [vp, vp, vp, sz, f32, vp, C.POINTER(Stats)]
         L.ptc_trace_rays_device.argtypes = [vp, vp, vp, sz, f32, vp]
@@ -473,6 +476,9 @@ class RenderResources:
         self.wavefront_bounces = 0  # 0 = library default
         self.max_paths_in_flight = 0  # 0 = library default (2^27)
         self.tonemap = TONEMAP_PBR_NEUTRAL  # the one the reference compiles in (shader.rgen:218-219)
+        # draw_frame() records its dispatch and returns, as the reference's does with its frames in flight
+        # (src/renderer.hpp:208); False = every draw_frame() launches its own dispatch at once
+        self.frames_in_flight = True
 
     @property
     def sample_count(self) -> int:
@@ -483,9 +489,11 @@ class RenderResources:
         _check(lib().ptc_film_set_sample_count(self.film, v))
 
     def render(self, camera: Camera, frame: int, samples_per_frame: int = 1, n_frames: int = 1,
-               frame_stride: int = 1, static: bool = False):
-        """ptc_render, or with static=True ptc_render_static (no allocation; the
-        library's static workspace bounds the paths of one dispatch)."""
+               frame_stride: int = 1, static: bool = False, deferred: bool = False):
+        """ptc_render; with static=True ptc_render_static (no allocation; the
+        library's static workspace bounds the paths of one dispatch); with
+        deferred=True ptc_render_deferred (recorded on the film, launched together
+        with the calls that continue it)."""
         p = RenderParams()
         p.global_frame_count = frame
         p.samples_per_frame = samples_per_frame
@@ -499,8 +507,12 @@ class RenderResources:
         p.wavefront_bounces = self.wavefront_bounces
         p.max_paths_in_flight = self.max_paths_in_flight
         p.tonemap = self.tonemap
-        call = lib().ptc_render_static if static else lib().ptc_render
+        call = lib().ptc_render_static if static else lib().ptc_render_deferred if deferred else lib().ptc_render
         _check(call(self.ctx.handle, self.scene.handle, self.film, C.byref(camera), C.byref(p)))
+
+    def flush(self):
+        """Launches the dispatches draw_frame() has recorded and not launched yet."""
+        _check(lib().ptc_film_flush(self.film))
 
     def read_accum(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 4), np.float32)
@@ -539,12 +551,15 @@ def create_render_resources(context: RenderContext, render_width: int, render_he
 def draw_frame(context: RenderContext, render_resources: RenderResources, camera: Camera) -> None:
     """The traced part of draw_frame() (src/renderer.cpp:2015-2130, :2224):
     renders min(remaining, samples_per_frame) samples when the target has not
-    been reached, and advances global_frame_count on every call."""
+    been reached, and advances global_frame_count on every call. Like the
+    reference's, the call returns once its dispatch is recorded
+    (src/renderer.cpp:2170-2172): consecutive calls with one camera are launched
+    together, at the latest when something reads the film."""
     rr = render_resources
     sc = rr.sample_count
     if sc < rr.samples_to_render:
         samples_this_frame = min(rr.samples_to_render - sc, rr.samples_per_frame)
-        rr.render(camera, context.global_frame_count, samples_this_frame)
+        rr.render(camera, context.global_frame_count, samples_this_frame, deferred=rr.frames_in_flight)
     context.global_frame_count = (context.global_frame_count + 1) & 0xFFFFFFFF
 
 

@@ -252,3 +252,57 @@ def test_draw_frames_equals_consecutive_draw_frame_calls(ctx):
     assert np.array_equal(_bits(films[0][0]), _bits(films[1][0]))
     assert np.array_equal(films[0][1], films[1][1])
     dev.close()
+
+
+def test_draw_frame_with_frames_in_flight_equals_immediate_dispatches(ctx):
+    """draw_frame() records its dispatch and returns; the recorded run is launched
+    as one batch when the camera changes, when the workspace bound is reached,
+    or when something reads the film. Film and counters equal those of a loop
+    that launches every dispatch at once, through a camera change, a partial
+    last dispatch, idle calls and a reset in the middle of a run."""
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(ctx, sc)
+    w, h = 48, 32
+    cam_a = R.default_camera(w, h)
+    cam_b = R.default_camera(w, h)
+    R.camera_set_distance(cam_b, 3.0)
+    out = []
+    for in_flight in (False, True):
+        rr = R.RenderResources(ctx, w, h, dev)
+        rr.frames_in_flight = in_flight
+        rr.max_depth = 6
+        rr.samples_to_render, rr.samples_per_frame = 31, 2
+        rr.max_paths_in_flight = 5 * w * h * 2  # a recorded run is launched after five dispatches at the latest
+        ctx.global_frame_count = 7
+        R.reset_render(rr)
+        for _ in range(3):
+            R.draw_frame(ctx, rr, cam_a)  # dropped by the reset below, as an overwritten film would be
+        R.reset_render(rr)
+        assert rr.sample_count == 0
+        ctx.reset_stats()
+        for k in range(7):
+            R.draw_frame(ctx, rr, cam_a)
+            assert rr.sample_count == 2 * (k + 1)  # recorded samples count
+        for _ in range(4):
+            R.draw_frame(ctx, rr, cam_b)  # another camera: the run so far is launched first
+        st = ctx.stats()  # launches what is recorded
+        assert st.paths == 11 * 2 * w * h
+        for _ in range(8):
+            R.draw_frame(ctx, rr, cam_b)  # 4 full dispatches, one of a single sample, three idle calls
+        assert rr.sample_count == 31 and ctx.global_frame_count == 7 + 3 + 19
+        out.append((rr.read_accum(), rr.read_rgba8(), ctx.stats().rays))
+        rr.close()
+    assert np.array_equal(_bits(out[0][0]), _bits(out[1][0]))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2]
+    # a recorded run is launched before its scene goes away, and dropped with its film
+    rr = R.RenderResources(ctx, w, h, R.DeviceScene(ctx, sc))
+    R.draw_frame(ctx, rr, cam_a)
+    rr.scene.close()
+    assert rr.sample_count == 1
+    rr.flush()
+    rr.close()
+    rr = R.RenderResources(ctx, w, h, dev)
+    R.draw_frame(ctx, rr, cam_a)
+    rr.close()
+    dev.close()

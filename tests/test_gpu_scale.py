@@ -114,6 +114,35 @@ def test_dragon_1080p_whole_bench_step_in_flight(dragon, ctx):
     assert (films[0][0][..., 3] == 256.0).all()
 
 
+def test_plain_draw_frame_loop_reaches_the_batched_rate(dragon, ctx):
+    """The reference's call pattern, one draw_frame() per frame at one sample per
+    frame: with its dispatches recorded and launched together the loop runs at
+    no less than 80 % of the rate of draw_frames(256), and leaves the same film."""
+    import time
+    sc, dev, orc = dragon
+    w, h = 1920, 1080
+    cam = R.default_camera(w, h)
+    films, secs = [], []
+    for plain_loop in (False, True, False, True):
+        rr = R.RenderResources(ctx, w, h, dev)
+        ctx.global_frame_count = 0
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        if plain_loop:
+            for _ in range(256):
+                R.draw_frame(ctx, rr, cam)
+        else:
+            R.draw_frames(ctx, rr, cam, 256)
+        ctx.synchronize()
+        secs.append(time.perf_counter() - t0)
+        assert rr.sample_count == 256
+        films.append(rr.read_accum())
+        rr.close()
+    assert np.array_equal(films[2].view(np.uint32), films[3].view(np.uint32))
+    print(f"256 spp at 1080p: draw_frames(256) {secs[2] * 1e3:.1f} ms, 256 x draw_frame() {secs[3] * 1e3:.1f} ms")
+    assert secs[2] / secs[3] >= 0.8  # (the first pair of runs warms the workspace up)
+
+
 def test_ten_million_triangles_build_and_trace(ctx, oracle):
     mesh = scenes.torus_mesh(3162, 1581)
     sc = R.Scene([mesh], [R.Instance(R.IDENTITY, 0, R.KIND_DIFFUSE)], None)

@@ -11,6 +11,13 @@ from collections import defaultdict
 
 
 def short(name):
+    # the counting variants of the render kernels (instrumented passes of bench.py, slower by design) are kept
+    # apart from the plain ones: k_wf_primary<pixel-major, two-level, counting>, k_render_mega<counting, two-level>
+    for k, arg in (("k_wf_primary<", 2), ("k_render_mega<", 0)):
+        if k in name:
+            args = name.split(k, 1)[1].split(">", 1)[0].split(",")
+            if len(args) > arg and args[arg].strip() == "true":
+                return k[:-1] + "_counting"
     for k in ("k_wf_primary", "k_wf_drain", "k_wf_trace", "k_wf_shade", "k_wf_resolve", "k_render_mega",
               "k_trace", "k_nearest", "k_wide_emit", "k_flatten"):
         if k in name:

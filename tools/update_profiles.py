@@ -40,10 +40,12 @@ for symbol, short in (("k_wf_drain", "drain"), ("k_wf_primary", "primary"), ("k_
     if not k or "FETCH_SIZE_per_dispatch" not in k:
         continue
     fetch_kb, write_kb = k["FETCH_SIZE_per_dispatch"], k["WRITE_SIZE_per_dispatch"]
-    cycles = k.get("GRBM_GUI_ACTIVE_per_dispatch") or 0.0
+    # rocprofv3 reports GRBM_GUI_ACTIVE summed over the chip's 8 XCDs
+    cycles = (k.get("GRBM_GUI_ACTIVE_per_dispatch") or 0.0) / 8.0
     entry = {
         "scene": a.scene, "width": a.width, "height": a.height, "spp_per_step": a.spp, "max_depth": a.max_depth,
         "kernel": short, "kernel_symbol": symbol, "mean_launch_us": k["mean_us"],
+        "clock_ghz": round(cycles / (k["mean_us"] * 1e3), 3) if cycles else None,
         "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
         # FETCH_SIZE tallies the 128-byte fabric requests of 16-byte-per-lane loads at 64 bytes on gfx950
         "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
