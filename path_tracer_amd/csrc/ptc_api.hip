@@ -555,6 +555,23 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
     S->info.n_triangles = (uint32_t)total;
     S->info.n_instances = n_instances;
 
+    BuildParams build_params;
+    if (opts)
+    {
+        build_params.search_radius = opts->search_radius;
+        build_params.collapse = opts->collapse;
+        build_params.tri_cost = opts->tri_cost;
+        if (opts->collapse > 1u || !(opts->tri_cost >= 0.0f) || opts->tri_cost > 64.0f)
+        {
+            set_error("ptc_scene_create: unknown collapse rule or triangle cost outside [0, 64]");
+            ptc_scene_destroy(S);
+            return PTC_E_INVALID;
+        }
+    }
+    if (const char *env = getenv("PTC_TRI_COST")) // measurement aid: overrides the triangle cost of the collapse
+    {
+        build_params.tri_cost = (float)atof(env);
+    }
     if (opts && opts->two_level)
     {
         // object-space box of every mesh, from the host arrays
@@ -575,11 +592,11 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
         {
             mesh_of[i] = instances[i].mesh;
         }
-        rc = build_two_level(ctx, S, inst, vtx_off, tri_off, mesh_box, mesh_of, opts->search_radius);
+        rc = build_two_level(ctx, S, inst, vtx_off, tri_off, mesh_box, mesh_of, build_params);
     }
     else
     {
-        rc = build_bvh(ctx, S, inst, (uint32_t)total, opts ? opts->search_radius : 0u);
+        rc = build_bvh(ctx, S, inst, (uint32_t)total, build_params);
     }
     if (rc != PTC_OK)
     {

@@ -15,10 +15,14 @@
 //                   Morton curve, the partner whose merged box has the smallest
 //                   surface area; mutual choices merge. This is the agglomerative
 //                   form of the surface-area heuristic.
-//   4. collapse     top-down, one wide level per launch: open the child with the
-//                   largest surface area until 8 slots are used; subtrees of <= 3
-//                   triangles become leaf slots; children are placed in slots so
-//                   that (slot XOR ray octant) orders them front to back
+//   4. collapse     which binary nodes become wide nodes, and which eight
+//                   subtrees become the children of each, is chosen bottom-up by
+//                   dynamic programming over the surface-area cost of the wide
+//                   tree (k_collapse_cost), then followed top-down, one wide level
+//                   per launch; subtrees of <= 3 triangles become leaf slots;
+//                   children are placed in slots so that (slot XOR ray octant)
+//                   orders them front to back. (collapse = 1 keeps the greedy
+//                   rule: open the child of largest area until 8 slots are used.)
 //   5. quantise     child boxes to 8 bits on a per-node power-of-two grid,
 //                   rounded outward against the float decode the traversal uses
 #include <string.h>
@@ -39,6 +43,7 @@ namespace
 constexpr int kBlock = 256;
 constexpr int kMaxRadius = 32;
 constexpr uint32_t kLeafMax = 3;
+constexpr float kDefaultTriCost = 0.45f;
 
 __device__ __forceinline__ uint32_t f2ord(float f)
 {
@@ -497,15 +502,185 @@ __device__ __forceinline__ float half_area(float4 lo, float4 hi)
     return dx * dy + dy * dz + dz * dx;
 }
 
+
+// Cost-optimal collapse. For a binary node n and a budget of i subtree roots
+// (1 <= i <= 7), cost[i-1] is the least surface-area cost of covering n's
+// triangles with at most i children of one wide node:
+//   i == 1: n itself is the child: a leaf slot (<= 3 triangles: area * count *
+//           tri_cost), or a wide node of its own (area * 1 + the cheapest way
+//           of covering its two halves with 8 roots between them);
+//   i >= 2: the cheaper of the budget split k : i - k between n's halves and of
+//           cost[i-2] (fewer roots than allowed).
+// Children have smaller ids than parents (they were clusters of earlier
+// rounds), so one launch per clustering round, in round order, sees finished
+// children. dec packs the choices: bits 3(i-1)..3(i-1)+2 = roots given to the
+// left half for budget i (0: use budget i - 1; for i == 1: 1 = wide node, 0 =
+// leaf slot), bits 21..23 = the left half's share of the 8 roots of a wide node
+// at n.
+struct CollapseCost
+{
+    float cost[7];
+    uint32_t dec;
+};
+
+__device__ __forceinline__ void collapse_cost_node(uint32_t id, uint32_t n_leaves, float tri_cost,
+                                                   const float4 *__restrict__ node_lo,
+                                                   const float4 *__restrict__ node_hi,
+                                                   const uint2 *__restrict__ node_lr,
+                                                   const CollapseCost &L, const CollapseCost &R,
+                                                   CollapseCost &out)
+{
+    const float4 lo = node_lo[id], hi = node_hi[id];
+    const float area = half_area(lo, hi);
+    const uint32_t cnt = __float_as_uint(lo.w);
+    uint32_t dec = 0u;
+    // the 8-way split of a wide node here
+    float best8 = INFINITY;
+    uint32_t k8 = 1u;
+    for (uint32_t k = 1; k <= 7u; ++k)
+    {
+        const float c = L.cost[k - 1u] + R.cost[7u - k];
+        if (c < best8)
+        {
+            best8 = c;
+            k8 = k;
+        }
+    }
+    dec |= k8 << 21;
+    if (cnt <= kLeafMax)
+    {
+        out.cost[0] = area * (float)cnt * tri_cost;
+    }
+    else
+    {
+        out.cost[0] = area + best8;
+        dec |= 1u;
+    }
+    for (uint32_t i = 2; i <= 7u; ++i)
+    {
+        float best = out.cost[i - 2u];
+        uint32_t bk = 0u;
+        for (uint32_t k = 1; k < i; ++k)
+        {
+            const float c = L.cost[k - 1u] + R.cost[i - k - 1u];
+            if (c < best)
+            {
+                best = c;
+                bk = k;
+            }
+        }
+        out.cost[i - 1u] = best;
+        dec |= bk << (3u * (i - 1u));
+    }
+    out.dec = dec;
+}
+
+// cost table of a child: a single triangle costs the same under every budget
+__device__ __forceinline__ CollapseCost collapse_cost_of(uint32_t id, uint32_t n_leaves, float tri_cost,
+                                                         const float4 *__restrict__ node_lo,
+                                                         const float4 *__restrict__ node_hi,
+                                                         const CollapseCost *__restrict__ table)
+{
+    if (id >= n_leaves)
+    {
+        return table[id - n_leaves];
+    }
+    CollapseCost c;
+    const float a = half_area(node_lo[id], node_hi[id]) * tri_cost;
+    for (int i = 0; i < 7; ++i)
+    {
+        c.cost[i] = a;
+    }
+    c.dec = 0u;
+    return c;
+}
+
+// internal binary nodes [first, last): the nodes of one clustering round
+__global__ void __launch_bounds__(kBlock)
+k_collapse_cost(uint32_t first, uint32_t last, uint32_t n_leaves, float tri_cost,
+                const float4 *__restrict__ node_lo, const float4 *__restrict__ node_hi,
+                const uint2 *__restrict__ node_lr, CollapseCost *__restrict__ table)
+{
+    const uint32_t id = first + blockIdx.x * kBlock + threadIdx.x;
+    if (id >= last)
+    {
+        return;
+    }
+    const uint2 lr = node_lr[id - n_leaves];
+    const CollapseCost L = collapse_cost_of(lr.x, n_leaves, tri_cost, node_lo, node_hi, table);
+    const CollapseCost R = collapse_cost_of(lr.y, n_leaves, tri_cost, node_lo, node_hi, table);
+    CollapseCost out;
+    collapse_cost_node(id, n_leaves, tri_cost, node_lo, node_hi, node_lr, L, R, out);
+    table[id - n_leaves] = out;
+}
+
+// The nodes [first, last) made by the one-block tail of the clustering
+// (k_ploc_tail), whose rounds the host does not see: one block, one thread per
+// node; a node is costed in the first pass that finds both children done.
+// Every pass completes at least the lowest unfinished node, so the loop ends.
+__global__ void __launch_bounds__(kTailMax)
+k_collapse_cost_tail(uint32_t first, uint32_t last, uint32_t n_leaves, float tri_cost,
+                     const float4 *__restrict__ node_lo, const float4 *__restrict__ node_hi,
+                     const uint2 *__restrict__ node_lr, CollapseCost *__restrict__ table)
+{
+    __shared__ CollapseCost s_table[kTailMax];
+    __shared__ uint32_t s_done[kTailMax];
+    __shared__ uint32_t s_left;
+    const uint32_t id = first + threadIdx.x;
+    const bool mine = id < last;
+    s_done[threadIdx.x] = 0u;
+    if (threadIdx.x == 0u)
+    {
+        s_left = last - first;
+    }
+    uint2 lr = make_uint2(0u, 0u);
+    if (mine)
+    {
+        lr = node_lr[id - n_leaves];
+    }
+    bool done = !mine;
+    __syncthreads();
+    for (uint32_t pass = 0; pass < (uint32_t)kTailMax; ++pass)
+    {
+        const bool l_ready = lr.x < first || s_done[lr.x - first] != 0u;
+        const bool r_ready = lr.y < first || s_done[lr.y - first] != 0u;
+        const bool go = !done && l_ready && r_ready;
+        CollapseCost out;
+        if (go)
+        {
+            const CollapseCost L = lr.x >= first ? s_table[lr.x - first]
+                                                 : collapse_cost_of(lr.x, n_leaves, tri_cost, node_lo, node_hi, table);
+            const CollapseCost R = lr.y >= first ? s_table[lr.y - first]
+                                                 : collapse_cost_of(lr.y, n_leaves, tri_cost, node_lo, node_hi, table);
+            collapse_cost_node(id, n_leaves, tri_cost, node_lo, node_hi, node_lr, L, R, out);
+        }
+        __syncthreads();
+        if (go)
+        {
+            s_table[threadIdx.x] = out;
+            s_done[threadIdx.x] = 1u;
+            table[id - n_leaves] = out;
+            done = true;
+            atomicSub(&s_left, 1u);
+        }
+        __syncthreads();
+        if (s_left == 0u)
+        {
+            break;
+        }
+    }
+}
+
 // For every wide node of the current level: pick its (up to 8) children among
 // the binary subtree below wide_root[w], count internal children and leaf
-// triangles.
+// triangles. table != nullptr: the children the cost table chose; nullptr: the
+// greedy rule (open the child of largest area until 8 slots are used).
 __global__ void __launch_bounds__(kBlock)
 k_wide_select(uint32_t level_start, uint32_t level_end, uint32_t n_leaves,
               const uint32_t *__restrict__ wide_root, const float4 *__restrict__ node_lo,
               const float4 *__restrict__ node_hi, const uint2 *__restrict__ node_lr,
-              uint32_t *__restrict__ sel_child, uint32_t *__restrict__ sel_n,
-              unsigned long long *__restrict__ counts)
+              const CollapseCost *__restrict__ table, uint32_t *__restrict__ sel_child,
+              uint32_t *__restrict__ sel_n, unsigned long long *__restrict__ counts)
 {
     const uint32_t w = level_start + blockIdx.x * kBlock + threadIdx.x;
     if (w >= level_end)
@@ -521,6 +696,47 @@ k_wide_select(uint32_t level_start, uint32_t level_end, uint32_t n_leaves,
         child[0] = b;
         area[0] = -1.0f;
         n = 1;
+    }
+    else if (table != nullptr)
+    {
+        // follow the recorded choices: a work list of (subtree, roots it may become)
+        uint32_t todo_id[8], todo_budget[8];
+        int top = 0;
+        const uint2 lr = node_lr[b - n_leaves];
+        const uint32_t k8 = (table[b - n_leaves].dec >> 21) & 7u;
+        todo_id[top] = lr.y;
+        todo_budget[top++] = 8u - k8;
+        todo_id[top] = lr.x;
+        todo_budget[top++] = k8;
+        n = 0;
+        while (top > 0)
+        {
+            const uint32_t m = todo_id[--top];
+            uint32_t j = todo_budget[top];
+            uint32_t k = 0u;
+            if (m >= n_leaves)
+            {
+                const uint32_t dec = table[m - n_leaves].dec;
+                while (j > 1u && (k = (dec >> (3u * (j - 1u))) & 7u) == 0u)
+                {
+                    --j;
+                }
+            }
+            if (m < n_leaves || j <= 1u || n + (uint32_t)top >= 7u)
+            {
+                child[n] = m;
+                area[n] = -1.0f;
+                ++n; // (the budgets on the list sum to at most 8 - n, each is >= 1: the last test never fires)
+            }
+            else
+            {
+                const uint2 lr2 = node_lr[m - n_leaves];
+                todo_id[top] = lr2.y;
+                todo_budget[top++] = j - k;
+                todo_id[top] = lr2.x;
+                todo_budget[top++] = k;
+            }
+        }
     }
     else
     {
@@ -892,13 +1108,17 @@ inline uint32_t blocks_for(size_t n)
 } // namespace
 
 int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &instances,
-              uint32_t n, uint32_t search_radius)
+              uint32_t n, const BuildParams &params)
 {
     hipStream_t st = ctx->stream;
-    const int radius = (int)std::min<uint32_t>(search_radius ? search_radius : 16u, kMaxRadius);
+    const int radius = (int)std::min<uint32_t>(params.search_radius ? params.search_radius : 16u, kMaxRadius);
+    // cost of one triangle test in units of one wide-node visit (a visit is five
+    // 16-byte fetches and eight box tests, a triangle test three fetches)
+    const float tri_cost = params.tri_cost > 0.0f ? params.tri_cost : kDefaultTriCost;
+    const bool greedy = params.collapse == 1u;
     TempPool pool;
     // about 390 bytes of scratch per triangle, plus the sort's and the scan's own
-    PTC_HIP_CHECK(pool.reserve((size_t)n * 480 + (1u << 20)));
+    PTC_HIP_CHECK(pool.reserve((size_t)n * 512 + (1u << 20)));
 
     // outputs
     const size_t node_cap = std::max<size_t>(n, 1);
@@ -969,6 +1189,12 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
         PTC_HIP_CHECK(pool.alloc(&wide_root, node_cap));
         PTC_HIP_CHECK(pool.alloc(&sel_child, node_cap * 8));
         PTC_HIP_CHECK(pool.alloc(&sel_n, node_cap));
+        CollapseCost *cost_table = nullptr;
+        if (!greedy)
+        {
+            PTC_HIP_CHECK(pool.alloc(&cost_table, n));
+        }
+        std::vector<std::pair<uint32_t, uint32_t>> round_nodes; // [first, last) node ids made by each clustering round
 
         const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
         PTC_HIP_CHECK(hipMemcpyAsync(bounds, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, st));
@@ -1016,6 +1242,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
                 return PTC_E_DEVICE;
             }
             n_cl = h_tot[0];
+            round_nodes.emplace_back(next_node, next_node + h_tot[1]);
             next_node += h_tot[1];
             cur ^= 1;
             if (++rounds > 4096)
@@ -1039,6 +1266,20 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
             next_node = h_tot[1];
         }
         const uint32_t binary_root = n == 1 ? 0u : next_node - 1u;
+        if (!greedy)
+        {
+            for (const auto &r : round_nodes)
+            {
+                k_collapse_cost<<<blocks_for(r.second - r.first), kBlock, 0, st>>>(r.first, r.second, n, tri_cost, node_lo,
+                                                                               node_hi, node_lr, cost_table);
+            }
+            const uint32_t tail_first = round_nodes.empty() ? n : round_nodes.back().second;
+            if (next_node > tail_first)
+            {
+                k_collapse_cost_tail<<<1, kTailMax, 0, st>>>(tail_first, next_node, n, tri_cost, node_lo, node_hi, node_lr,
+                                                             cost_table);
+            }
+        }
 
         // collapse, one wide level per pass
         PTC_HIP_CHECK(hipMemcpyAsync(wide_root, &binary_root, 4, hipMemcpyHostToDevice, st));
@@ -1059,7 +1300,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
         {
             const uint32_t cnt = level_end - level_start;
             k_wide_select<<<blocks_for(cnt), kBlock, 0, st>>>(level_start, level_end, n, wide_root, node_lo,
-                                                             node_hi, node_lr, sel_child, sel_n, flags);
+                                                             node_hi, node_lr, cost_table, sel_child, sel_n, flags);
             tmp_bytes = prim_bytes;
             PTC_HIP_CHECK(rocprim::exclusive_scan(prim_tmp, tmp_bytes, flags, scan, 0ULL, cnt,
                                                   rocprim::plus<unsigned long long>(), st));
@@ -1149,7 +1390,7 @@ k_rebase_nodes(uint4 *__restrict__ nodes, uint32_t n_nodes, uint32_t node_off, u
 int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &instances,
                     const std::vector<uint32_t> &vtx_off, const std::vector<uint32_t> &tri_off,
                     const std::vector<float> &mesh_box, const std::vector<uint32_t> &mesh_of,
-                    uint32_t search_radius)
+                    const BuildParams &params)
 {
     hipStream_t st = ctx->stream;
     const uint32_t n_meshes = (uint32_t)vtx_off.size() - 1u;
@@ -1204,7 +1445,7 @@ int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &
         sub.d_indices = scene->d_indices;
         sub.d_instances = d_pseudo + m;
         const std::vector<DInstance> one(1, pseudo[m]);
-        const int rc = build_bvh(ctx, &sub, one, nt, search_radius);
+        const int rc = build_bvh(ctx, &sub, one, nt, params);
         built[m].nodes = sub.d_nodes;
         built[m].tris = sub.d_tris;
         if (rc != PTC_OK)

@@ -146,17 +146,25 @@ struct PhaseTimer
     }
 };
 
+// What ptc_build_options says about the tree (0 = default everywhere).
+struct BuildParams
+{
+    uint32_t search_radius = 0;
+    uint32_t collapse = 0; // 0: cost-optimal choice of the wide nodes; 1: greedy by area
+    float tri_cost = 0.0f; // cost of a triangle test relative to a node visit
+};
+
 // BVH build on the device (ptc_bvh_build.hip). Fills scene->d_nodes, d_tris,
 // d.nodes, d.tris and the BVH fields of scene->info.
 int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &instances,
-              uint32_t n_flat_tris, uint32_t search_radius);
+              uint32_t n_flat_tris, const BuildParams &params);
 // Two-level variant: one tree per mesh in object space (concatenated into
 // d_nodes / d_tris), instances[i].blas_root and the world boxes in d_inst_box.
 // mesh_box holds (lo.xyz, hi.xyz) of every mesh in object space.
 int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &instances,
                     const std::vector<uint32_t> &vtx_off, const std::vector<uint32_t> &tri_off,
                     const std::vector<float> &mesh_box, const std::vector<uint32_t> &mesh_of,
-                    uint32_t search_radius);
+                    const BuildParams &params);
 
 // Render kernels (ptc_render.hip, ptc_wavefront.hip).
 int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const DFrame &frame,

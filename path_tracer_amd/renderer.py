@@ -88,7 +88,8 @@ IMPORT_NO_NORMALIZE, IMPORT_NO_JOIN = 1, 2
 
 
 class BuildOptions(C.Structure):
-    _fields_ = [("search_radius", C.c_uint32), ("two_level", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+    _fields_ = [("search_radius", C.c_uint32), ("two_level", C.c_uint32), ("collapse", C.c_uint32),
+                ("tri_cost", C.c_float), ("reserved", C.c_uint32 * 4)]
 
 
 class SceneInfo(C.Structure):
@@ -378,7 +379,8 @@ def create_context(device: int = 0) -> RenderContext:
 
 
 class DeviceScene:
-    def __init__(self, ctx: RenderContext, scene: Scene, search_radius: int = 0, two_level: bool = False):
+    def __init__(self, ctx: RenderContext, scene: Scene, search_radius: int = 0, two_level: bool = False,
+                 collapse: int = 0, tri_cost: float = 0.0):
         self.ctx = ctx
         self.two_level = two_level
         keep = []
@@ -406,6 +408,8 @@ class DeviceScene:
         opts = BuildOptions()
         opts.search_radius = search_radius
         opts.two_level = int(two_level)
+        opts.collapse = collapse
+        opts.tri_cost = tri_cost
         h = C.c_void_p()
         _check(lib().ptc_scene_create(ctx.handle, md, len(scene.meshes), idesc,
                                       len(scene.instances), C.byref(env) if env else None,
