@@ -398,7 +398,10 @@ int ptc_read_hdr(const char *file_name, uint32_t *width, uint32_t *height, float
  * and points removed), FixInfacingNormals, GenSmoothNormals with a maximum
  * smoothing angle of 80 degrees and JoinIdenticalVertices, then reads
  * mVertices / mNormals / mFaces of the meshes. This importer reads Wavefront
- * OBJ and Stanford PLY (ascii and binary) files and applies the same steps;
+ * OBJ and Stanford PLY (ascii and binary) files and applies the same steps
+ * with Assimp's tolerances (quads cut from their concave corner, larger
+ * polygons ear-clipped; smoothing over corners within 1e-4 of the bounding-box
+ * diagonal; joining within 1e-5);
  * mesh i is returned as the ptc_mesh_desc that ptc_scene_create() takes.
  * Pointers in the descriptor stay valid until ptc_mesh_file_close().
  * Failure: PTC_E_IO with the importer's message ("Scene has no meshes", ...)
@@ -406,11 +409,19 @@ int ptc_read_hdr(const char *file_name, uint32_t *width, uint32_t *height, float
 typedef struct ptc_mesh_file ptc_mesh_file;
 #define PTC_IMPORT_NO_NORMALIZE 1u /* keep file coordinates (no AI_CONFIG_PP_PTV_NORMALIZE) */
 #define PTC_IMPORT_NO_JOIN 2u      /* keep one vertex per triangle corner */
+#define PTC_IMPORT_EXACT_MATCH 4u  /* smoothing and joining match positions and normals bit for bit */
+#define PTC_IMPORT_FAN 8u          /* every polygon is split as a fan from its first corner */
 typedef struct ptc_import_options
 {
     float max_smoothing_angle_deg; /* AI_CONFIG_PP_GSN_MAX_SMOOTHING_ANGLE; 0 = 80 */
     uint32_t flags;                /* PTC_IMPORT_* */
-    uint32_t reserved[6];
+    /* GenSmoothNormals treats corners as one position when they lie within this
+     * fraction of the diagonal of the mesh's bounding box; 0 = Assimp's 1e-4. */
+    float position_epsilon_rel;
+    /* JoinIdenticalVertices joins a corner with an earlier vertex whose position
+     * and normal are both within this distance; 0 = Assimp's 1e-5. */
+    float join_epsilon;
+    uint32_t reserved[4];
 } ptc_import_options;
 int ptc_mesh_file_open(const char *file_name, const ptc_import_options *options, ptc_mesh_file **out);
 uint32_t ptc_mesh_file_mesh_count(const ptc_mesh_file *file);

@@ -6,16 +6,22 @@
 // file restates the published behaviour of the post-processing steps the
 // reference asks for, in Assimp's fixed step order:
 //   PreTransformVertices + AI_CONFIG_PP_PTV_NORMALIZE  scene bbox -> [-1, 1]
-//   Triangulate                                         fan from corner 0
+//   Triangulate                                         quads from their concave
+//                                                       corner, larger polygons by
+//                                                       ear clipping
 //   FindDegenerates (area check off) + SortByPType      drop triangles with two
 //     removing lines and points                         equal corner positions
 //   FixInfacingNormals                                  bbox-growth heuristic
-//   GenSmoothNormals, max angle 80 degrees              only if the file has none
-//   JoinIdenticalVertices                               exact (position, normal)
+//   GenSmoothNormals, max angle 80 degrees              only if the file has none;
+//                                                       corners within 1e-4 of the
+//                                                       mesh's bbox diagonal share
+//   JoinIdenticalVertices                               position and normal within
+//                                                       1e-5 of an earlier vertex
 // for Wavefront OBJ and Stanford PLY (ascii, binary little / big endian) files.
-// Differences from Assimp that can change vertices: coincident positions are
-// matched exactly (Assimp uses 1e-4 of the bbox diagonal when smoothing and
-// 1e-5 when joining), concave polygons are fan- rather than ear-triangulated.
+// Where Assimp's result depends on the order in which its spatial sort or its
+// hash map hands out candidates, this importer goes by ascending corner index
+// (sums) and by the earliest vertex (joins). PTC_IMPORT_EXACT_MATCH and
+// PTC_IMPORT_FAN select bit-exact position matching and fan triangulation.
 // Host code only: no device work happens here.
 #include "ptc_internal.h"
 
@@ -562,22 +568,252 @@ struct KeyHash
     }
 };
 
+// Positions within a distance: a grid of cells as wide as the distance over the
+// distinct positions (most corners of a mesh share their position with others
+// bit for bit, so the search runs once per distinct position).
+struct Cell
+{
+    int64_t x, y, z;
+    bool operator==(const Cell &o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct CellHash
+{
+    size_t operator()(const Cell &c) const
+    {
+        uint64_t h = (uint64_t)c.x * 0x9e3779b97f4a7c15ull;
+        h = (h ^ (uint64_t)c.y) * 0xbf58476d1ce4e5b9ull;
+        h = (h ^ (uint64_t)c.z) * 0x94d049bb133111ebull;
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+
+struct PositionIndex
+{
+    std::vector<V3> unique;               // distinct positions, in order of first use
+    std::vector<uint32_t> unique_of;      // per input position: its distinct position
+    std::vector<std::vector<uint32_t>> near; // per distinct position: distinct positions within the distance (itself first)
+
+    // radius <= 0: bit-exact matching only
+    PositionIndex(const std::vector<V3> &pos, float radius)
+    {
+        std::unordered_map<Key3, uint32_t, KeyHash> ids;
+        ids.reserve(pos.size() / 2);
+        unique_of.resize(pos.size());
+        for (size_t i = 0; i < pos.size(); ++i)
+        {
+            const Key3 k {bits(pos[i].x), bits(pos[i].y), bits(pos[i].z)};
+            auto it = ids.find(k);
+            if (it == ids.end())
+            {
+                it = ids.emplace(k, (uint32_t)unique.size()).first;
+                unique.push_back(pos[i]);
+            }
+            unique_of[i] = it->second;
+        }
+        near.resize(unique.size());
+        for (uint32_t u = 0; u < unique.size(); ++u)
+        {
+            near[u].push_back(u);
+        }
+        if (!(radius > 0.0f))
+        {
+            return;
+        }
+        const double inv = 1.0 / (double)radius;
+        auto cell_of = [&](V3 v) { return Cell {(int64_t)std::floor(v.x * inv), (int64_t)std::floor(v.y * inv), (int64_t)std::floor(v.z * inv)}; };
+        std::unordered_map<Cell, std::vector<uint32_t>, CellHash> grid;
+        grid.reserve(unique.size());
+        for (uint32_t u = 0; u < unique.size(); ++u)
+        {
+            grid[cell_of(unique[u])].push_back(u);
+        }
+        const float r2 = radius * radius;
+        for (uint32_t u = 0; u < unique.size(); ++u)
+        {
+            const Cell c = cell_of(unique[u]);
+            for (int dz = -1; dz <= 1; ++dz)
+            {
+                for (int dy = -1; dy <= 1; ++dy)
+                {
+                    for (int dx = -1; dx <= 1; ++dx)
+                    {
+                        auto it = grid.find(Cell {c.x + dx, c.y + dy, c.z + dz});
+                        if (it == grid.end())
+                        {
+                            continue;
+                        }
+                        for (uint32_t w : it->second)
+                        {
+                            const V3 d = unique[w] - unique[u];
+                            if (w != u && dot(d, d) < r2)
+                            {
+                                near[u].push_back(w);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+double area2(double ax, double ay, double bx, double by, double cx, double cy)
+{
+    return (bx - ax) * (cy - ay) - (cx - ax) * (by - ay); // twice the signed area of (a, b, c)
+}
+
+// Splits one polygon (corner indices c[0..n)) into triangles, as local corner
+// numbers. Triangles stay; a quad is cut from its concave corner when it has
+// one (the angles its two edges make with the diagonal there add up to more
+// than pi), else from corner 0; larger polygons are ear-clipped in the plane
+// their Newell normal points out of: going round from the last ear, the first
+// convex corner whose triangle holds none of the other corners is cut off. A
+// polygon without an ear (not simple) falls back to the fan from corner 0.
+void split_polygon(const V3 *pts, uint32_t n, bool fan, std::vector<uint32_t> &out)
+{
+    out.clear();
+    if (n < 3)
+    {
+        return;
+    }
+    auto fan_from = [&](uint32_t start) {
+        for (uint32_t k = 2; k < n; ++k)
+        {
+            out.insert(out.end(), {start, (start + k - 1) % n, (start + k) % n});
+        }
+    };
+    if (n == 3 || fan)
+    {
+        fan_from(0);
+        return;
+    }
+    if (n == 4)
+    {
+        uint32_t start = 0;
+        for (uint32_t i = 0; i < 4; ++i)
+        {
+            const V3 v = pts[i];
+            const V3 left = normalize_safe(pts[(i + 3) % 4] - v), diag = normalize_safe(pts[(i + 2) % 4] - v),
+                     right = normalize_safe(pts[(i + 1) % 4] - v);
+            auto clamped = [](float x) { return x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x); };
+            const float angle = std::acos(clamped(dot(left, diag))) + std::acos(clamped(dot(right, diag)));
+            if (angle > 3.14159265358979323846f)
+            {
+                start = i;
+                break;
+            }
+        }
+        fan_from(start);
+        return;
+    }
+    // Newell normal, then the projection that drops its largest component
+    double nx = 0.0, ny = 0.0, nz = 0.0;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const V3 a = pts[i], b = pts[(i + 1) % n];
+        nx += ((double)a.y - b.y) * ((double)a.z + b.z);
+        ny += ((double)a.z - b.z) * ((double)a.x + b.x);
+        nz += ((double)a.x - b.x) * ((double)a.y + b.y);
+    }
+    const double ax = std::fabs(nx), ay = std::fabs(ny), az = std::fabs(nz);
+    int drop = az >= ax && az >= ay ? 2 : (ay >= ax ? 1 : 0);
+    const double sign = drop == 2 ? nz : (drop == 1 ? ny : nx);
+    std::vector<double> px(n), py(n);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const double c[3] = {pts[i].x, pts[i].y, pts[i].z};
+        double u = c[(drop + 1) % 3], v = c[(drop + 2) % 3];
+        if (sign < 0.0)
+        {
+            std::swap(u, v); // keeps the polygon counter-clockwise in the plane
+        }
+        px[i] = u;
+        py[i] = v;
+    }
+    std::vector<char> done(n, 0);
+    uint32_t left = n, ear = 0;
+    auto next_of = [&](uint32_t i) {
+        do
+        {
+            i = (i + 1) % n;
+        } while (done[i]);
+        return i;
+    };
+    auto prev_of = [&](uint32_t i) {
+        do
+        {
+            i = (i + n - 1) % n;
+        } while (done[i]);
+        return i;
+    };
+    while (left > 3)
+    {
+        bool found = false;
+        uint32_t e = ear;
+        for (uint32_t tries = 0; tries < left; ++tries, e = next_of(e))
+        {
+            const uint32_t a = prev_of(e), b = next_of(e);
+            if (!(area2(px[a], py[a], px[e], py[e], px[b], py[b]) > 0.0))
+            {
+                continue; // reflex or flat corner
+            }
+            bool holds_other = false;
+            for (uint32_t t = 0; t < n && !holds_other; ++t)
+            {
+                if ((px[t] == px[a] && py[t] == py[a]) || (px[t] == px[e] && py[t] == py[e]) ||
+                    (px[t] == px[b] && py[t] == py[b]))
+                {
+                    continue; // several corners may name one position
+                }
+                holds_other = area2(px[a], py[a], px[e], py[e], px[t], py[t]) >= 0.0 &&
+                              area2(px[e], py[e], px[b], py[b], px[t], py[t]) >= 0.0 &&
+                              area2(px[b], py[b], px[a], py[a], px[t], py[t]) >= 0.0;
+            }
+            if (!holds_other)
+            {
+                out.insert(out.end(), {a, e, b});
+                done[e] = 1;
+                --left;
+                ear = b;
+                found = true;
+                break;
+            }
+        }
+        if (!found)
+        {
+            out.clear();
+            fan_from(0);
+            return;
+        }
+    }
+    const uint32_t a = next_of(n - 1), b = next_of(a), c = next_of(b);
+    out.insert(out.end(), {a, b, c});
+}
+
 // Triangulate + FindDegenerates: triangle corners in "verbose" form (one vertex
 // per corner), triangles with two coincident corners dropped.
-std::vector<Corner> triangulate(const RawMesh &m)
+std::vector<Corner> triangulate(const RawMesh &m, bool fan)
 {
     std::vector<Corner> tri;
+    std::vector<V3> pts;
+    std::vector<uint32_t> local;
     for (size_t f = 0; f + 1 < m.face_start.size(); ++f)
     {
         const uint32_t b = m.face_start[f], e = m.face_start[f + 1];
-        for (uint32_t k = b + 2; k < e; ++k)
+        pts.clear();
+        for (uint32_t k = b; k < e; ++k)
         {
-            const uint32_t c[3] = {b, k - 1, k};
+            pts.push_back(m.positions[m.corner_pos[k]]);
+        }
+        split_polygon(pts.data(), e - b, fan, local);
+        for (size_t t = 0; t + 2 < local.size(); t += 3)
+        {
             Corner v[3];
             for (int j = 0; j < 3; ++j)
             {
-                v[j].p = m.positions[m.corner_pos[c[j]]];
-                v[j].n = m.has_normals() ? m.normals[m.corner_nrm[c[j]]] : V3 {0, 0, 0};
+                const uint32_t c = b + local[t + j];
+                v[j].p = m.positions[m.corner_pos[c]];
+                v[j].n = m.has_normals() ? m.normals[m.corner_nrm[c]] : V3 {0, 0, 0};
             }
             auto same = [](V3 a, V3 b2) { return a.x == b2.x && a.y == b2.y && a.z == b2.z; };
             if (same(v[0].p, v[1].p) || same(v[1].p, v[2].p) || same(v[0].p, v[2].p))
@@ -590,44 +826,61 @@ std::vector<Corner> triangulate(const RawMesh &m)
     return tri;
 }
 
+// The distance within which GenSmoothNormals takes two corners to be at one
+// position: rel (1e-4) of the diagonal of the mesh's bounding box.
+float position_epsilon(const std::vector<Corner> &tri, float rel)
+{
+    V3 lo {1e10f, 1e10f, 1e10f}, hi {-1e10f, -1e10f, -1e10f};
+    for (const Corner &c : tri)
+    {
+        lo = {std::min(lo.x, c.p.x), std::min(lo.y, c.p.y), std::min(lo.z, c.p.z)};
+        hi = {std::max(hi.x, c.p.x), std::max(hi.y, c.p.y), std::max(hi.z, c.p.z)};
+    }
+    const V3 d = hi - lo;
+    return std::sqrt(dot(d, d)) * rel;
+}
+
 // GenSmoothNormals: every corner gets the normalised sum of the face normals of
-// all corners at the same position whose face normal is within max_angle of
-// its own.
-void smooth_normals(std::vector<Corner> &tri, float max_angle_deg)
+// all corners within `radius` of its position (0: at its position bit for bit)
+// whose face normal is within max_angle of its own, summed in corner order.
+void smooth_normals(std::vector<Corner> &tri, float max_angle_deg, float radius)
 {
     const size_t n = tri.size();
-    std::vector<V3> face(n);
+    std::vector<V3> face(n), pos(n);
     for (size_t t = 0; t < n; t += 3)
     {
         const V3 fn = normalize_safe(cross(tri[t + 1].p - tri[t].p, tri[t + 2].p - tri[t].p));
         face[t] = face[t + 1] = face[t + 2] = fn;
+        pos[t] = tri[t].p;
+        pos[t + 1] = tri[t + 1].p;
+        pos[t + 2] = tri[t + 2].p;
     }
-    // corners grouped by position: head[] / next[] chains
-    std::unordered_map<Key3, uint32_t, KeyHash> head;
-    head.reserve(n / 2);
-    std::vector<uint32_t> next(n, 0xffffffffu);
+    const PositionIndex index(pos, radius);
+    std::vector<std::vector<uint32_t>> corners_at(index.unique.size()); // ascending
     for (size_t i = 0; i < n; ++i)
     {
-        const Key3 k {bits(tri[i].p.x), bits(tri[i].p.y), bits(tri[i].p.z)};
-        auto it = head.find(k);
-        if (it == head.end())
-        {
-            head.emplace(k, (uint32_t)i);
-        }
-        else
-        {
-            next[i] = it->second;
-            it->second = (uint32_t)i;
-        }
+        corners_at[index.unique_of[i]].push_back((uint32_t)i);
     }
     const float limit = std::cos(max_angle_deg * 3.14159265358979323846f / 180.0f);
     const bool unlimited = max_angle_deg >= 175.0f;
+    std::vector<uint32_t> merged;
     for (size_t i = 0; i < n; ++i)
     {
-        const Key3 k {bits(tri[i].p.x), bits(tri[i].p.y), bits(tri[i].p.z)};
+        const std::vector<uint32_t> &nb = index.near[index.unique_of[i]];
+        const std::vector<uint32_t> *list = &corners_at[nb[0]];
+        if (nb.size() > 1)
+        {
+            merged.clear();
+            for (uint32_t u : nb)
+            {
+                merged.insert(merged.end(), corners_at[u].begin(), corners_at[u].end());
+            }
+            std::sort(merged.begin(), merged.end());
+            list = &merged;
+        }
         const V3 vr = face[i];
         V3 sum {0, 0, 0};
-        for (uint32_t j = head[k]; j != 0xffffffffu; j = next[j])
+        for (uint32_t j : *list)
         {
             const V3 v = face[j];
             if (v.x != v.x)
@@ -685,30 +938,70 @@ void fix_infacing_normals(std::vector<Corner> &tri)
     }
 }
 
-// JoinIdenticalVertices: one vertex per distinct (position, normal).
-void join_vertices(const std::vector<Corner> &tri, bool join, ptc_mesh_file::Mesh &out)
+// JoinIdenticalVertices: a corner becomes the earliest vertex made so far whose
+// position and normal are both within `eps` of its own (eps 0: equal bit for
+// bit), else a new vertex.
+void join_vertices(const std::vector<Corner> &tri, bool join, float eps, ptc_mesh_file::Mesh &out)
 {
-    std::unordered_map<Key6, uint32_t, KeyHash> seen;
-    seen.reserve(tri.size() / 4);
     out.indices.reserve(tri.size());
-    for (const Corner &c : tri)
+    auto emit = [&](const Corner &c) {
+        const uint32_t id = (uint32_t)(out.positions.size() / 3);
+        out.positions.insert(out.positions.end(), {c.p.x, c.p.y, c.p.z});
+        out.normals.insert(out.normals.end(), {c.n.x, c.n.y, c.n.z});
+        return id;
+    };
+    if (!join)
     {
-        uint32_t id;
-        const Key6 k {{bits(c.p.x), bits(c.p.y), bits(c.p.z), bits(c.n.x), bits(c.n.y), bits(c.n.z)}};
-        auto it = join ? seen.find(k) : seen.end();
-        if (it == seen.end())
+        for (const Corner &c : tri)
         {
-            id = (uint32_t)(out.positions.size() / 3);
-            out.positions.insert(out.positions.end(), {c.p.x, c.p.y, c.p.z});
-            out.normals.insert(out.normals.end(), {c.n.x, c.n.y, c.n.z});
-            if (join)
+            out.indices.push_back(emit(c));
+        }
+        return;
+    }
+    if (!(eps > 0.0f))
+    {
+        std::unordered_map<Key6, uint32_t, KeyHash> seen;
+        seen.reserve(tri.size() / 4);
+        for (const Corner &c : tri)
+        {
+            const Key6 k {{bits(c.p.x), bits(c.p.y), bits(c.p.z), bits(c.n.x), bits(c.n.y), bits(c.n.z)}};
+            auto it = seen.find(k);
+            if (it == seen.end())
             {
-                seen.emplace(k, id);
+                it = seen.emplace(k, emit(c)).first;
+            }
+            out.indices.push_back(it->second);
+        }
+        return;
+    }
+    std::vector<V3> pos(tri.size());
+    for (size_t i = 0; i < tri.size(); ++i)
+    {
+        pos[i] = tri[i].p;
+    }
+    const PositionIndex index(pos, eps);
+    std::vector<std::vector<uint32_t>> made_at(index.unique.size()); // vertices made at a distinct position, ascending
+    const float e2 = eps * eps;
+    for (size_t i = 0; i < tri.size(); ++i)
+    {
+        const Corner &c = tri[i];
+        const uint32_t u = index.unique_of[i];
+        uint32_t id = 0xffffffffu;
+        for (uint32_t w : index.near[u])
+        {
+            for (uint32_t v : made_at[w])
+            {
+                const V3 dn = V3 {out.normals[3 * (size_t)v], out.normals[3 * (size_t)v + 1], out.normals[3 * (size_t)v + 2]} - c.n;
+                if (v < id && !(dot(dn, dn) > e2))
+                {
+                    id = v;
+                }
             }
         }
-        else
+        if (id == 0xffffffffu)
         {
-            id = it->second;
+            id = emit(c);
+            made_at[u].push_back(id);
         }
         out.indices.push_back(id);
     }
@@ -745,6 +1038,10 @@ extern "C" int ptc_mesh_file_open(const char *file_name, const ptc_import_option
                                 ? options->max_smoothing_angle_deg
                                 : 80.0f; // src/application.cpp:155
     const uint32_t flags = options != nullptr ? options->flags : 0u;
+    const bool exact = (flags & PTC_IMPORT_EXACT_MATCH) != 0u;
+    // ComputePositionEpsilon() of Assimp's smoothing step and the epsilon of its join step
+    const float smooth_rel = exact ? 0.0f : (options != nullptr && options->position_epsilon_rel > 0.0f ? options->position_epsilon_rel : 1e-4f);
+    const float join_eps = exact ? 0.0f : (options != nullptr && options->join_epsilon > 0.0f ? options->join_epsilon : 1e-5f);
     try
     {
         const std::vector<char> data = read_file(file_name);
@@ -792,18 +1089,18 @@ extern "C" int ptc_mesh_file_open(const char *file_name, const ptc_import_option
         std::unique_ptr<ptc_mesh_file> file(new ptc_mesh_file);
         for (const RawMesh &m : raw)
         {
-            std::vector<Corner> tri = triangulate(m);
+            std::vector<Corner> tri = triangulate(m, (flags & PTC_IMPORT_FAN) != 0u);
             if (tri.empty())
             {
                 continue;
             }
             if (!m.has_normals())
             {
-                smooth_normals(tri, max_angle);
+                smooth_normals(tri, max_angle, smooth_rel > 0.0f ? position_epsilon(tri, smooth_rel) : 0.0f);
             }
             fix_infacing_normals(tri);
             ptc_mesh_file::Mesh mesh;
-            join_vertices(tri, !(flags & PTC_IMPORT_NO_JOIN), mesh);
+            join_vertices(tri, !(flags & PTC_IMPORT_NO_JOIN), join_eps, mesh);
             file->meshes.push_back(std::move(mesh));
         }
         if (file->meshes.empty())

@@ -81,10 +81,11 @@ class EnvmapDesc(C.Structure):
 
 
 class ImportOptions(C.Structure):
-    _fields_ = [("max_smoothing_angle_deg", C.c_float), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+    _fields_ = [("max_smoothing_angle_deg", C.c_float), ("flags", C.c_uint32), ("position_epsilon_rel", C.c_float),
+                ("join_epsilon", C.c_float), ("reserved", C.c_uint32 * 4)]
 
 
-IMPORT_NO_NORMALIZE, IMPORT_NO_JOIN = 1, 2
+IMPORT_NO_NORMALIZE, IMPORT_NO_JOIN, IMPORT_EXACT_MATCH, IMPORT_FAN = 1, 2, 4, 8
 
 
 class BuildOptions(C.Structure):
@@ -591,7 +592,8 @@ def reset_render(render_resources: RenderResources) -> None:
 
 
 def import_meshes(file_name: str, max_smoothing_angle: float = 80.0, normalize: bool = True,
-                  join_identical_vertices: bool = True) -> list:
+                  join_identical_vertices: bool = True, exact_match: bool = False, fan: bool = False,
+                  position_epsilon_rel: float = 0.0, join_epsilon: float = 0.0) -> list:
     """The import half of open_scene() (src/application.cpp:150-200): reads a
     Wavefront OBJ or Stanford PLY file and post-processes it the way the
     reference configures Assimp (normalise to [-1, 1], triangulate, drop
@@ -600,7 +602,10 @@ def import_meshes(file_name: str, max_smoothing_angle: float = 80.0, normalize: 
     importer's message otherwise."""
     opts = ImportOptions()
     opts.max_smoothing_angle_deg = max_smoothing_angle
-    opts.flags = (0 if normalize else IMPORT_NO_NORMALIZE) | (0 if join_identical_vertices else IMPORT_NO_JOIN)
+    opts.flags = ((0 if normalize else IMPORT_NO_NORMALIZE) | (0 if join_identical_vertices else IMPORT_NO_JOIN) |
+                  (IMPORT_EXACT_MATCH if exact_match else 0) | (IMPORT_FAN if fan else 0))
+    opts.position_epsilon_rel = position_epsilon_rel
+    opts.join_epsilon = join_epsilon
     h = C.c_void_p()
     _check(lib().ptc_mesh_file_open(os.fsencode(file_name), C.byref(opts), C.byref(h)))
     try:

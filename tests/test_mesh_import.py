@@ -172,3 +172,125 @@ def test_import_errors(tmp_path, content, name, reason):
         R.import_meshes(str(path))
     with pytest.raises(R.PtcError, match="Unable to open file"):
         R.import_meshes(str(tmp_path / "missing.obj"))
+
+
+def test_seam_within_the_position_tolerance_is_smoothed_and_joined(tmp_path):
+    """Two halves of a curved sheet whose seam vertices are written twice, a few
+    1e-6 apart: within 1e-4 of the bounding-box diagonal the seam's corners
+    share their smoothed normals, and within 1e-5 they become one vertex.
+    Bit-exact matching leaves the seam split and creased."""
+    nu, nv = 9, 7
+    u, v = np.meshgrid(np.linspace(-1, 1, nu), np.linspace(-1, 1, nv), indexing="ij")
+    grid = np.stack([u, v, 0.3 * np.cos(2 * u) * np.cos(v)], axis=-1).astype(np.float32)
+    left = grid[: nu // 2 + 1].reshape(-1, 3)
+    right = grid[nu // 2:].reshape(-1, 3).copy()
+    right[:nv] += np.array([2e-6, -3e-6, 1e-6], np.float32)  # the seam column again, slightly off
+    p = np.concatenate([left, right])
+    quad = lambda base, i, j: [base + i * nv + j, base + (i + 1) * nv + j, base + (i + 1) * nv + j + 1, base + i * nv + j + 1]
+    faces = [quad(0, i, j) for i in range(nu // 2) for j in range(nv - 1)]
+    faces += [quad(len(left), i, j) for i in range(nu - nu // 2 - 1) for j in range(nv - 1)]
+    path = tmp_path / "seam.ply"
+    write_ply(path, p, faces, "binary_little_endian")
+    meshes = R.import_meshes(str(path), normalize=False)
+    rp, rn, ri = M.import_polygons(p, faces, 80.0, normalize=False)
+    m = meshes[0]
+    assert np.array_equal(m.indices, ri)
+    assert np.array_equal(_bits(m.positions), _bits(rp)) and np.array_equal(_bits(m.normals), _bits(rn))
+    assert m.positions.shape[0] == nu * nv  # the doubled seam column collapsed
+    exact = R.import_meshes(str(path), normalize=False, exact_match=True)[0]
+    ep, en, ei = M.import_polygons(p, faces, 80.0, normalize=False, exact=True)
+    assert np.array_equal(exact.indices, ei) and np.array_equal(_bits(exact.normals), _bits(en))
+    assert exact.positions.shape[0] == nu * nv + nv
+    # wider tolerances through the options: everything within 0.6 of a corner smooths and joins with it
+    wide = R.import_meshes(str(path), normalize=False, position_epsilon_rel=0.2, join_epsilon=0.3)[0]
+    wp, wn, wi = M.import_polygons(p, faces, 80.0, normalize=False, position_epsilon_rel=0.2, join_epsilon=0.3)
+    assert np.array_equal(wide.indices, wi) and np.array_equal(_bits(wide.normals), _bits(wn))
+    assert wide.positions.shape[0] < m.positions.shape[0]
+
+
+def _polygon_area(p, face):
+    q = p[face]
+    return 0.5 * np.linalg.norm(sum(np.cross(q[i], q[(i + 1) % len(face)]) for i in range(len(face))))
+
+
+def test_concave_polygons_are_cut_inside_their_outline(tmp_path):
+    """An arrowhead quad, an L-shaped hexagon, a star and a spiral-like comb in
+    three different planes: the triangles tile the polygon (areas add up, all
+    with one orientation), where a fan from corner 0 would not."""
+    arrow = [[0, 0, 0], [2, 1, 0], [0, 2, 0], [0.5, 1, 0]]                      # concave at corner 3
+    ell = [[0, 0, 1], [3, 0, 1], [3, 1, 1], [1, 1, 1], [1, 3, 1], [0, 3, 1]]
+    ang = np.arange(10) * (np.pi / 5)
+    rad = np.where(np.arange(10) % 2 == 0, 2.0, 0.7)
+    star = np.stack([np.zeros(10) + 5, rad * np.cos(ang), rad * np.sin(ang)], axis=1)   # in a plane x = 5
+    comb = [[0, 9, 0], [7, 9, 0], [7, 9, 3], [6, 9, 3], [6, 9, 1], [4, 9, 1], [4, 9, 3], [3, 9, 3], [3, 9, 1], [1, 9, 1],
+            [1, 9, 3], [0, 9, 3]]                                                  # in a plane y = 9, clockwise seen from +y
+    p = np.concatenate([np.asarray(a, np.float32) for a in (arrow, ell, star, comb)])
+    faces, base = [], 0
+    for poly in (arrow, ell, star, comb):
+        faces.append(list(range(base, base + len(poly))))
+        base += len(poly)
+    path = tmp_path / "concave.obj"
+    write_obj(path, p, faces)
+    meshes = R.import_meshes(str(path), normalize=False, join_identical_vertices=False)
+    rp, rn, ri = M.import_polygons(p, faces, 80.0, normalize=False, join_epsilon=0.0, exact=False)
+    m = meshes[0]
+    assert m.indices.shape[0] == sum(len(f) - 2 for f in faces)
+    tri = m.positions[m.indices.reshape(-1)].reshape(-1, 3, 3).astype(np.float64)
+    cr = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    first = 0
+    for f in faces:
+        k = len(f) - 2
+        nrm = sum(np.cross(p[f[i]].astype(np.float64), p[f[(i + 1) % len(f)]].astype(np.float64)) for i in range(len(f)))
+        c = cr[first:first + k]
+        assert np.all(c @ nrm > 0) or np.all(c @ nrm < 0)  # one orientation (FixInfacingNormals may turn the mesh over)
+        assert np.isclose(0.5 * np.linalg.norm(c, axis=1).sum(), _polygon_area(p.astype(np.float64), f), rtol=1e-6)
+        first += k
+    # the same triangles as the restatement (one vertex per corner, in order)
+    got = m.positions[m.indices.reshape(-1)]
+    want = rp[ri.reshape(-1)]
+    assert np.array_equal(_bits(got), _bits(want))
+    # a fan from corner 0 leaves the arrowhead's outline: the option brings it back for comparison
+    fan = R.import_meshes(str(path), normalize=False, fan=True)[0]
+    ftri = fan.positions[fan.indices.reshape(-1)].reshape(-1, 3, 3).astype(np.float64)
+    fcr = np.cross(ftri[:, 1] - ftri[:, 0], ftri[:, 2] - ftri[:, 0])
+    assert 0.5 * np.linalg.norm(fcr, axis=1).sum() > sum(_polygon_area(p.astype(np.float64), f) for f in faces) * 1.05
+
+
+def test_binary_ply_of_871k_triangles_round_trips(tmp_path):
+    """The headline mesh size through the importer: a binary PLY without normals
+    comes back with the same triangles and unit normals close to the
+    area-weighted ones, in a time that is printed; without an angle limit there
+    is one vertex per position (the limit of 80 degrees splits the mesh's scale
+    edges), and bit-exact matching finds the same vertices (no two of its
+    positions are closer than the tolerances)."""
+    import time
+    mesh = scenes.knot_mesh()
+    path = tmp_path / "knot.ply"
+    nv, nt = mesh.positions.shape[0], mesh.indices.shape[0]
+    assert nt == 871402
+    with open(path, "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {nv}\nproperty float x\nproperty float y\n"
+                 f"property float z\nelement face {nt}\nproperty list uchar int vertex_indices\nend_header\n").encode())
+        f.write(np.ascontiguousarray(mesh.positions, "<f4").tobytes())
+        rec = np.empty(nt, np.dtype([("n", "u1"), ("i", "<i4", 3)]))
+        rec["n"], rec["i"] = 3, mesh.indices
+        f.write(rec.tobytes())
+    t0 = time.perf_counter()
+    m = R.import_meshes(str(path), normalize=False)[0]
+    dt = time.perf_counter() - t0
+    print(f"import of {nt:,} triangles / {nv:,} vertices from binary PLY: {dt:.2f} s")
+    assert m.indices.shape == (nt, 3)
+    assert np.array_equal(_bits(m.positions[m.indices.reshape(-1)]), _bits(mesh.positions[mesh.indices.reshape(-1)]))
+    n_positions = np.unique(mesh.positions, axis=0).shape[0]
+    assert m.positions.shape[0] >= n_positions
+    assert R.import_meshes(str(path), normalize=False, max_smoothing_angle=175.0)[0].positions.shape[0] == n_positions
+    exact = R.import_meshes(str(path), normalize=False, exact_match=True)[0]
+    assert np.array_equal(exact.indices, m.indices) and np.array_equal(_bits(exact.normals), _bits(m.normals))
+    assert np.allclose(np.linalg.norm(m.normals, axis=1), 1.0, atol=1e-5)
+    # every corner's normal lies within the 80-degree limit of its own face normal
+    tri = mesh.positions[mesh.indices.reshape(-1)].reshape(-1, 3, 3)
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    got = m.normals[m.indices.reshape(-1)].reshape(-1, 3, 3)
+    assert np.all((got * fn[:, None, :]).sum(axis=2) > np.cos(np.radians(80.0)) - 1e-4)
+    assert dt < 60.0
