@@ -345,6 +345,14 @@ int ptc_primary_hits(ptc_context *ctx, const ptc_scene *scene,
                      uint32_t global_frame_count, float tmax,
                      uint32_t *ids_out);
 
+/* Flattened triangle indices (ptc_primary_hits, ptc_hit::flat) as the pair a
+ * closest-hit shader of the reference reads: gl_InstanceID (index into the
+ * instance list, src/renderer.cpp:1147-1174) and gl_PrimitiveID (triangle
+ * within the instance's mesh, closest_hit_common.glsl:61-64). PTC_NO_HIT and
+ * indices beyond the scene give PTC_NO_HIT for both. Host-side; no GPU work. */
+int ptc_scene_triangle_ids(const ptc_scene *scene, const uint32_t *flat, size_t n,
+                           uint32_t *instance_out, uint32_t *primitive_out);
+
 /* Closest-hit queries for caller-supplied rays: one traceRayEXT each
  * (shader.rgen:68-78: opaque, no culling, tmin 0). rays = 6 floats per ray
  * (origin, direction). Host pointers. counters may be NULL; when given the

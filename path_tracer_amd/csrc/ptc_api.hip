@@ -485,6 +485,11 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
         set_error("ptc_scene_create: empty environment map");
         return PTC_E_INVALID;
     }
+    if (envmap && envmap->rgba && (uint64_t)envmap->width * envmap->height > (1ull << 28))
+    {
+        set_error("ptc_scene_create: environment map beyond 2^28 texels");
+        return PTC_E_LIMIT;
+    }
 
     ptc_scene *S = new (std::nothrow) ptc_scene();
     if (!S)
@@ -493,6 +498,10 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
         return PTC_E_NOMEM;
     }
     S->ctx = ctx;
+    for (const DInstance &D : inst)
+    {
+        S->first_flat.push_back(D.first_flat);
+    }
     int rc = PTC_OK;
     auto fail = [&](int code) {
         ptc_scene_destroy(S);
@@ -1103,6 +1112,30 @@ int ptc_primary_hits(ptc_context *ctx, const ptc_scene *scene, const ptc_camera 
     }
     (void)hipFree(d_ids);
     return rc;
+}
+
+int ptc_scene_triangle_ids(const ptc_scene *scene, const uint32_t *flat, size_t n, uint32_t *instance_out,
+                           uint32_t *primitive_out)
+{
+    if (!scene || (n && (!flat || !instance_out || !primitive_out)))
+    {
+        set_error("ptc_scene_triangle_ids: NULL argument");
+        return PTC_E_INVALID;
+    }
+    const std::vector<uint32_t> &first = scene->first_flat;
+    for (size_t i = 0; i < n; ++i)
+    {
+        if (flat[i] == PTC_NO_HIT || flat[i] >= scene->info.n_triangles)
+        {
+            instance_out[i] = primitive_out[i] = PTC_NO_HIT;
+            continue;
+        }
+        // the last instance that starts at or before the index (instances without triangles share a start)
+        const size_t k = (size_t)(std::upper_bound(first.begin(), first.end(), flat[i]) - first.begin()) - 1u;
+        instance_out[i] = (uint32_t)k;
+        primitive_out[i] = flat[i] - first[k];
+    }
+    return PTC_OK;
 }
 
 int ptc_trace_rays_device(ptc_context *ctx, const ptc_scene *scene, const void *rays_dev, size_t n_rays,

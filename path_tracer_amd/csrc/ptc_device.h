@@ -344,10 +344,16 @@ PTC_DEV Payload closest_hit(const DScene &S, vec3 ray_dir, const Hit &h, uint32_
 
 // ---- miss program: shader.rmiss:11-29 ----------------------------------------
 
+// i modulo n into [0, n) (repeat addressing). Texel coordinates of directions on
+// the unit sphere land in [-1, n], so the division is a rare fallback.
 PTC_DEV int wrap_index(int i, int n)
 {
-    const int r = i % n;
-    return r < 0 ? r + n : r;
+    if (__builtin_expect(i < -n || i >= 2 * n, 0))
+    {
+        const int r = i % n;
+        return r < 0 ? r + n : r;
+    }
+    return i < 0 ? i + n : (i >= n ? i - n : i);
 }
 
 // bilinear, repeat addressing, no mips (src/renderer.cpp:861-878)
@@ -369,10 +375,12 @@ PTC_DEV vec3 env_lookup(const DScene &S, float u, float v)
     const int x1 = wrap_index((int)x0f + 1, (int)S.env_w);
     const int y0 = wrap_index((int)y0f, (int)S.env_h);
     const int y1 = wrap_index((int)y0f + 1, (int)S.env_h);
-    const float4 t00 = S.env[(size_t)y0 * S.env_w + x0];
-    const float4 t10 = S.env[(size_t)y0 * S.env_w + x1];
-    const float4 t01 = S.env[(size_t)y1 * S.env_w + x0];
-    const float4 t11 = S.env[(size_t)y1 * S.env_w + x1];
+    // (32-bit texel numbers: ptc_scene_create bounds the map at 2^28 texels)
+    const uint32_t row0 = (uint32_t)y0 * S.env_w, row1 = (uint32_t)y1 * S.env_w;
+    const float4 t00 = S.env[row0 + (uint32_t)x0];
+    const float4 t10 = S.env[row0 + (uint32_t)x1];
+    const float4 t01 = S.env[row1 + (uint32_t)x0];
+    const float4 t11 = S.env[row1 + (uint32_t)x1];
     const float gx = 1.0f - fx, gy = 1.0f - fy;
     vec3 c;
     c.x = (t00.x * gx + t10.x * fx) * gy + (t01.x * gx + t11.x * fx) * fy;

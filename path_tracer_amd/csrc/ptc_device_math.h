@@ -175,7 +175,11 @@ PTC_DEV float asin_core(float z)
     return __builtin_fmaf(p * z2, z, z);
 }
 
-// acos with the argument clamped to [-1, 1]
+// acos with the argument clamped to [-1, 1]:
+//   x >  0.5: 2 asin(sqrt((1 - x) / 2));  x < -0.5: pi - 2 asin(sqrt((1 + x) / 2));
+//   else pi / 2 - asin(x).
+// (One square root and one polynomial serve the three ranges: 1 + x is the same
+// single operation as 1 - |x| for a negative x.)
 PTC_DEV float acos_(float x)
 {
     if (!(x < 1.0f))
@@ -186,34 +190,28 @@ PTC_DEV float acos_(float x)
     {
         return kPi;
     }
+    const bool outer = x > 0.5f || x < -0.5f;
+    const float root = __builtin_sqrtf(0.5f * (1.0f - __builtin_fabsf(x)));
+    const float a = asin_core(outer ? root : x);
     if (x > 0.5f)
     {
-        return 2.0f * asin_core(__builtin_sqrtf(0.5f * (1.0f - x)));
+        return 2.0f * a;
     }
     if (x < -0.5f)
     {
-        return kPi - 2.0f * asin_core(__builtin_sqrtf(0.5f * (1.0f + x)));
+        return kPi - 2.0f * a;
     }
-    return 1.57079632679489661923f - asin_core(x);
+    return 1.57079632679489661923f - a;
 }
 
+// atan of t >= 0: t > tan(3 pi / 8): pi / 2 + atan(-1 / t); t > tan(pi / 8):
+// pi / 4 + atan((t - 1) / (t + 1)); one division serves both reductions.
 PTC_DEV float atan_core(float t)
 {
-    float y0;
-    if (t > 2.414213562373095f)
-    {
-        y0 = 1.57079632679489661923f;
-        t = -1.0f / t;
-    }
-    else if (t > 0.4142135623730950f)
-    {
-        y0 = 0.785398163397448309616f;
-        t = (t - 1.0f) / (t + 1.0f);
-    }
-    else
-    {
-        y0 = 0.0f;
-    }
+    const bool high = t > 2.414213562373095f, mid = !high && t > 0.4142135623730950f;
+    const float y0 = high ? 1.57079632679489661923f : (mid ? 0.785398163397448309616f : 0.0f);
+    const float q = (high ? -1.0f : t - 1.0f) / (high ? t : t + 1.0f);
+    t = (high || mid) ? q : t;
     const float z = t * t;
     float p = __builtin_fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
     p = __builtin_fmaf(p, z, 1.99777106478e-1f);

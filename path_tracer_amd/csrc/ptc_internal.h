@@ -82,6 +82,7 @@ struct ptc_scene
     ptc::DInstance *d_instances = nullptr;
     float4 *d_inst_box = nullptr; // two-level scenes: (lo, hi) world box per instance
     float4 *d_env = nullptr;
+    std::vector<uint32_t> first_flat; // per instance: flattened index of its primitive 0 (ascending)
     ptc_scene_info info{};
 };
 

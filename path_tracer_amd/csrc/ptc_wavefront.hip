@@ -98,27 +98,6 @@ PTC_DEV uint32_t lane_id()
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-// Appends the calling lanes for which alive is true to a queue; returns the
-// slot. One atomic per wave.
-PTC_DEV uint32_t queue_append(bool alive, uint32_t *counter)
-{
-    const unsigned long long mask = __ballot(alive);
-    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
-    const uint32_t lane = lane_id();
-    uint32_t base = 0;
-    if (n != 0u)
-    {
-        const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-        if (lane == leader)
-        {
-            base = atomicAdd(counter, n);
-        }
-        base = __shfl(base, (int)leader, 64);
-    }
-    const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-    return base + rank;
-}
-
 PTC_DEV void store_state(const WfState &q, uint32_t slot, const PathState &ps, uint32_t pid)
 {
     q.a[slot] = make_float4(ps.origin.x, ps.origin.y, ps.origin.z, __uint_as_float(ps.rng));
@@ -150,8 +129,10 @@ PTC_DEV PathState camera_path(const DFrame &F, uint32_t px, uint32_t py, uint32_
 }
 
 constexpr int kPrimaryLds = 8; // LDS stack entries per lane: 16 KB per block, so registers (not LDS) set the occupancy
+// kMapping: 0 = a wave is an 8x8 pixel tile of one dispatch; 1 = a wave is 2 or 4
+// pixels with 32 or 16 dispatches each; 2 = a wave is one pixel with 64 dispatches.
 // kCount: also count nodes / triangles visited (reproducible visit order, slower).
-template <bool kPixelMajor, bool kTwoLevel, bool kCount>
+template <int kMapping, bool kTwoLevel, bool kCount>
 __global__ void __launch_bounds__(kBlock)
 k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_first, uint32_t sample,
              uint32_t n_disp, uint32_t lane_bits, DeviceStats *__restrict__ stats)
@@ -163,6 +144,7 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
     const uint32_t groups_x = (tiles_x + 7u) >> 3;
     uint32_t px, py, k;
     bool inside;
+    constexpr bool kPixelMajor = kMapping != 0;
     if (kPixelMajor)
     {
         // A wave is one pixel, its lanes are 64 dispatches of that pixel: the 64
@@ -175,7 +157,13 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
         // 32 or 16 dispatches each: lane_bits = log2 of the lanes per pixel.)
         const uint32_t lanes_per_pixel = 1u << lane_bits, pixels_per_block = kBlock >> lane_bits;
         const uint32_t k_groups = (n_disp + lanes_per_pixel - 1u) >> lane_bits;
-        const uint32_t q = (blockIdx.x / k_groups) * pixels_per_block + (threadIdx.x >> lane_bits); // pixel number
+        uint32_t q = (blockIdx.x / k_groups) * pixels_per_block + (threadIdx.x >> lane_bits); // pixel number
+        if (kMapping == 2)
+        {
+            // one pixel per wave: the pixel's coordinates, its index and the hash of
+            // it are the same in every lane and are computed on the scalar unit
+            q = __builtin_amdgcn_readfirstlane(q);
+        }
         k = (blockIdx.x % k_groups) * lanes_per_pixel + (threadIdx.x & (lanes_per_pixel - 1u));
         const uint32_t tile = q >> 8, l = q & 255u;
         const uint32_t group = tile >> 6, m = tile & 63u;
@@ -202,7 +190,9 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
         inside = px < F.width && py < F.height; // false for all lanes of tiles past the edge
     }
     bool alive = false;
-    PathState ps = camera_path(F, 0u, 0u, 0u);
+    PathState ps; // (lanes outside the film never read it)
+    ps.origin = ps.dir = ps.throughput = ps.radiance = v3(0.0f, 0.0f, 0.0f);
+    ps.rng = 0u;
     uint32_t pid = 0;
     if (inside)
     {
@@ -295,13 +285,21 @@ k_wf_trace(DScene S, float tmax, WfState q, float4 *__restrict__ hit, uint2 *__r
     }
 }
 
-__global__ void __launch_bounds__(kBlock)
+// Shading of one bounce for every queue slot: material / sky, emission, Russian
+// roulette; survivors go to the other queue. 1024 threads per block and one
+// append per block and round (the sixteen waves' counts are combined in LDS):
+// adds of every wave of the chip to the one counter would serialise in L2 at
+// about 10 ns each, 16 ms for the 1.6 M waves of a 100 M-path bounce.
+constexpr int kShadeBlock = 1024;
+__global__ void __launch_bounds__(kShadeBlock)
 k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
 {
+    __shared__ uint32_t s_alive[kShadeBlock / 64];
     const WfState qi = B.q[src], qo = B.q[src ^ 1];
     const uint32_t n = B.counts[bounce];
-    const uint32_t n_round = (n + 63u) & ~63u; // whole waves enter so ballots see every lane
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_round = (n + kShadeBlock - 1u) / kShadeBlock * kShadeBlock; // whole blocks enter: every thread meets the barriers
+    for (uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x; i < n_round; i += gridDim.x * kShadeBlock)
     {
         bool alive = false;
         PathState ps;
@@ -324,11 +322,40 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
                 finish_path(B, pid, ps.radiance, ps.rng);
             }
         }
-        const uint32_t slot = queue_append(alive, &B.counts[bounce + 1u]);
+        const unsigned long long mask = __ballot(alive);
+        if (lane == 0u)
+        {
+            s_alive[wave] = (uint32_t)__builtin_popcountll(mask);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64u)
+        {
+            // inclusive prefix sums of the sixteen wave counts, then one atomic
+            uint32_t v = threadIdx.x < kShadeBlock / 64 ? s_alive[threadIdx.x] : 0u;
+            for (int off = 1; off < kShadeBlock / 64; off <<= 1)
+            {
+                const uint32_t up = __shfl_up(v, off, 64);
+                v += lane >= (uint32_t)off ? up : 0u;
+            }
+            const uint32_t total = __shfl(v, kShadeBlock / 64 - 1, 64);
+            uint32_t base = 0u;
+            if (threadIdx.x == 0u && total != 0u)
+            {
+                base = atomicAdd(&B.counts[bounce + 1u], total);
+            }
+            base = __shfl(base, 0, 64);
+            if (threadIdx.x < kShadeBlock / 64)
+            {
+                s_alive[threadIdx.x] = base + v - s_alive[threadIdx.x]; // first slot of each wave
+            }
+        }
+        __syncthreads();
         if (alive)
         {
+            const uint32_t slot = s_alive[wave] + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
             store_state(qo, slot, ps, pid);
         }
+        __syncthreads(); // s_alive is rewritten in the next round
     }
 }
 
@@ -438,7 +465,9 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // rarer phases (pulling new paths, shading, triangle tests) run when
     // enough lanes of the wave want them, or when a lane has nothing else left.
     constexpr uint32_t kIdle = 0u, kTrav = 1u, kShade = 2u;
-    constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 16u, kTriMoreMin = 16u; // lanes that must want a phase before it runs
+    // lanes that must want a phase before it runs (swept again with the traversal state parked in LDS: 12 to 24
+    // lanes for each of the three are within 1 % of one another, 8 and 32 cost 3 to 7 %)
+    constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 16u, kTriMoreMin = 16u;
     uint32_t mode = kIdle;
     constexpr uint32_t kChunk = 128u; // work items a wave reserves per atomic
     uint32_t chunk_next = 0u, chunk_end = 0u; // this wave's reserved items not handed out yet
@@ -1092,13 +1121,18 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
                     const uint32_t grid = pixel_blocks * k_groups;
                     if (count)
                     {
-                        two_level ? launch(k_wf_primary<true, true, true>, grid, lane_bits)
-                                  : launch(k_wf_primary<true, false, true>, grid, lane_bits);
+                        two_level ? launch(k_wf_primary<1, true, true>, grid, lane_bits)
+                                  : launch(k_wf_primary<1, false, true>, grid, lane_bits);
+                    }
+                    else if (lane_bits == 6u)
+                    {
+                        two_level ? launch(k_wf_primary<2, true, false>, grid, lane_bits)
+                                  : launch(k_wf_primary<2, false, false>, grid, lane_bits);
                     }
                     else
                     {
-                        two_level ? launch(k_wf_primary<true, true, false>, grid, lane_bits)
-                                  : launch(k_wf_primary<true, false, false>, grid, lane_bits);
+                        two_level ? launch(k_wf_primary<1, true, false>, grid, lane_bits)
+                                  : launch(k_wf_primary<1, false, false>, grid, lane_bits);
                     }
                 }
                 else
@@ -1106,13 +1140,13 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
                     const uint32_t grid = tiles * nb;
                     if (count)
                     {
-                        two_level ? launch(k_wf_primary<false, true, true>, grid, 0u)
-                                  : launch(k_wf_primary<false, false, true>, grid, 0u);
+                        two_level ? launch(k_wf_primary<0, true, true>, grid, 0u)
+                                  : launch(k_wf_primary<0, false, true>, grid, 0u);
                     }
                     else
                     {
-                        two_level ? launch(k_wf_primary<false, true, false>, grid, 0u)
-                                  : launch(k_wf_primary<false, false, false>, grid, 0u);
+                        two_level ? launch(k_wf_primary<0, true, false>, grid, 0u)
+                                  : launch(k_wf_primary<0, false, false>, grid, 0u);
                     }
                 }
             }
@@ -1124,7 +1158,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
                 PhaseTimer timer(ctx, PTC_PHASE_BOUNCE);
                 const int src = (int)(b & 1u); // the primary pass writes set 1
                 k_wf_trace<<<blocks, kBlock, 0, st>>>(scene->d, F0.tmax, B.q[src], B.hit, B.hit_ids, B.counts + b);
-                k_wf_shade<<<blocks, kBlock, 0, st>>>(scene->d, B, b, F0.max_depth, src);
+                k_wf_shade<<<std::max(1u, blocks / (kShadeBlock / kBlock)), kShadeBlock, 0, st>>>(scene->d, B, b, F0.max_depth, src);
             }
             // whatever is still alive runs to its end in one persistent launch
             if (drain_b < F0.max_depth)

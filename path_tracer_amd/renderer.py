@@ -124,7 +124,7 @@ EXPORTS = [
     "ptc_film_create", "ptc_film_destroy", "ptc_film_reset", "ptc_film_sample_count",
     "ptc_film_set_sample_count", "ptc_film_read_accum", "ptc_film_read_rgba8",
     "ptc_film_accum_device_ptr", "ptc_film_resolve", "ptc_render", "ptc_render_static", "ptc_render_deferred", "ptc_film_flush",
-    "ptc_primary_hits",
+    "ptc_primary_hits", "ptc_scene_triangle_ids",
     "ptc_trace_rays", "ptc_trace_rays_device", "ptc_get_stats", "ptc_render_times",
     "ptc_phase_times",
     "ptc_reset_stats",
@@ -170,6 +170,7 @@ def lib():
         L.ptc_render_deferred.argtypes = [vp, vp, vp, C.POINTER(Camera), C.POINTER(RenderParams)]
         L.ptc_film_flush.argtypes = [vp]
         L.ptc_primary_hits.argtypes = [vp, vp, C.POINTER(Camera), u32, u32, u32, f32, vp]
+        L.ptc_scene_triangle_ids.argtypes = [vp, vp, sz, vp, vp]
         L.ptc_trace_rays.argtypes = [vp, vp, vp, sz, f32, vp, C.POINTER(Stats)]
         L.ptc_trace_rays_device.argtypes = [vp, vp, vp, sz, f32, vp]
         L.ptc_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -442,6 +443,14 @@ class DeviceScene:
         _check(lib().ptc_primary_hits(self.ctx.handle, self.handle, C.byref(camera), width,
                                       height, frame, tmax, ids.ctypes.data))
         return ids
+
+    def triangle_ids(self, flat):
+        """(instance, primitive) of flattened triangle indices: what gl_InstanceID /
+        gl_PrimitiveID would read in the reference's closest-hit shaders."""
+        flat = np.ascontiguousarray(flat, dtype=np.uint32)
+        inst, prim = np.empty_like(flat), np.empty_like(flat)
+        _check(lib().ptc_scene_triangle_ids(self.handle, flat.ctypes.data, flat.size, inst.ctypes.data, prim.ctypes.data))
+        return inst, prim
 
     def close(self):
         if self.handle:

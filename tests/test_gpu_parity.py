@@ -100,6 +100,14 @@ def test_primary_hit_ids(scene_pair, oracle):
         ref = orc.primary_hits(oracle.make_push(cam.as_dict(), frame=frame), w, h,
                                use_bvh=orc.n_triangles > 2000)
         assert np.array_equal(ids, ref), f"{name}: {np.count_nonzero(ids != ref)} primary ids differ"
+    # the same hits as (gl_InstanceID, gl_PrimitiveID) pairs
+    inst, prim = dev.triangle_ids(ids)
+    miss = ids == R.NO_HIT
+    assert np.all(inst[miss] == R.NO_HIT) and np.all(prim[miss] == R.NO_HIT)
+    counts = np.array([sc.meshes[i.mesh].indices.shape[0] for i in sc.instances], np.int64)
+    first = np.concatenate([[0], np.cumsum(counts)])
+    assert np.all(prim[~miss] < counts[inst[~miss]])
+    assert np.array_equal(first[inst[~miss]] + prim[~miss], ids[~miss])
 
 
 @pytest.mark.parametrize("integrator", [R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM],

@@ -12,7 +12,7 @@ from collections import defaultdict
 
 def short(name):
     # the counting variants of the render kernels (instrumented passes of bench.py, slower by design) are kept
-    # apart from the plain ones: k_wf_primary<pixel-major, two-level, counting>, k_render_mega<counting, two-level>
+    # apart from the plain ones: k_wf_primary<mapping, two-level, counting>, k_render_mega<counting, two-level>
     for k, arg in (("k_wf_primary<", 2), ("k_render_mega<", 0)):
         if k in name:
             args = name.split(k, 1)[1].split(">", 1)[0].split(",")
