@@ -361,6 +361,10 @@ def main():
                          "nodes_per_ray": round(nodes_d / max(rays_d, 1), 2),
                          "node_fetches_per_ray": round(fetches_d / max(rays_d, 1), 2),
                          "tris_per_ray": round(tris_d / max(rays_d, 1), 2),
+                         # the coherent first bounce, counted in the primary kernel itself
+                         "primary_nodes_per_ray": round(P["nodes"] / max(P["rays"], 1), 2),
+                         "primary_node_fetches_per_ray": round(node_fetches(P) / max(P["rays"], 1), 3),
+                         "primary_tris_per_ray": round(P["tris"] / max(P["rays"], 1), 2),
                          "phase_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in phases.items() if v[1]},
                          "note": f"node + triangle working set {ws_mb:.0f} MB "
                                  + ("fits the 256 MB Infinity Cache: HBM peak is the contract's stated bound, but "
