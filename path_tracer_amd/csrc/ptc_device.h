@@ -636,6 +636,19 @@ PTC_DEV Hit no_hit(float tmax)
     return h;
 }
 
+// A ray with a non-finite origin or direction (a path that met a degenerate
+// normal, say) can hit nothing: every comparison of the triangle test fails on
+// a NaN, and an infinite coordinate makes the barycentrics infinite or NaN. It
+// must not enter the tree either: the box test takes hardware minima / maxima,
+// which drop NaNs, so it would pass every box and the ray would walk all nodes
+// and triangles (one such ray among 10^8 made a launch twenty times longer).
+PTC_DEV bool ray_is_finite(vec3 o, vec3 d)
+{
+    // x * 0 is 0 for finite x and NaN for an infinity or a NaN
+    const float z = ((o.x * 0.0f + o.y * 0.0f) + (o.z * 0.0f + d.x * 0.0f)) + (d.y * 0.0f + d.z * 0.0f);
+    return z == 0.0f;
+}
+
 // A node group is (first internal child, hit bits 31..24 | imask 7..0): bit
 // 24 + (slot ^ octinv) set = that slot's box was hit and is still to be
 // visited; the highest bit is the nearest. A triangle group is (first triangle,
@@ -844,7 +857,7 @@ PTC_DEV Hit trace_closest(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *ld
                           uint32_t stride, TraceCounters *ctr, uint32_t root = 0u)
 {
     Hit best = no_hit(tmax);
-    if (S.n_tris == 0u)
+    if (S.n_tris == 0u || !ray_is_finite(o, d))
     {
         return best;
     }
@@ -899,7 +912,7 @@ PTC_DEV Hit trace_closest_interleaved(const DScene &S, vec3 o, vec3 d, float tma
                                       uint32_t stride, uint32_t root = 0u)
 {
     Hit best = no_hit(tmax);
-    if (S.n_tris == 0u)
+    if (S.n_tris == 0u || !ray_is_finite(o, d))
     {
         return best;
     }
@@ -1010,7 +1023,7 @@ PTC_DEV Hit trace_two_level(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *
                             TraceCounters *ctr)
 {
     Hit best = no_hit(tmax);
-    uint32_t pos = 0u;
+    uint32_t pos = ray_is_finite(o, d) ? 0u : S.n_inst_nodes; // a non-finite ray meets no instance
     for (uint32_t i = next_instance(S, pos, o, d, best.t); i != kNoInstance;
          i = next_instance(S, pos, o, d, best.t))
     {

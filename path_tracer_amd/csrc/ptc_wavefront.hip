@@ -540,6 +540,8 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // then 7 further rounds run, 8 shading phases, 9 iterations
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_begin = t_prev;
+    uint32_t ray_iters = 0u, ray_iters_max = 0u; // kProfile: loop iterations of the lane's current ray, and the most any of its rays took
 #define PTC_PROF(k)                                                     \
     if (kProfile)                                                       \
     {                                                                   \
@@ -711,18 +713,24 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
         }
         PTC_PROF(2)
         wave_rays += (uint32_t)__builtin_popcountll(__ballot(start));
+        if (kProfile)
+        {
+            ray_iters = start ? 0u : ray_iters + 1u;
+            ray_iters_max = ray_iters > ray_iters_max ? ray_iters : ray_iters_max;
+        }
         if (start)
         {
             best = no_hit(tmax);
+            const bool finite = ray_is_finite(org, dir); // a non-finite ray hits nothing and must not enter the tree
             if (kTwoLevel)
             {
-                inst_pos = 0u; // the first instance is looked for below
+                inst_pos = finite ? 0u : S.n_inst_nodes; // the first instance is looked for below
                 ng = make_uint2(0u, 0u);
             }
             else
             {
                 set_ray(org, dir, tmax);
-                ng = make_uint2(0u, S.n_tris != 0u ? 0x80000000u : 0u);
+                ng = make_uint2(0u, S.n_tris != 0u && finite ? 0x80000000u : 0u);
             }
             tg = make_uint2(0u, 0u);
             sp = 0;
@@ -847,11 +855,18 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     }
 #undef PTC_PROF
 #undef PTC_WORD
-    if (kProfile && lane == 0u)
+    if (kProfile)
     {
-        for (int k = 0; k < 10; ++k)
+        // 10: most iterations of one wave; 11: most cycles of one wave; 12: most iterations of one ray
+        atomicMax(&g_drain_prof[12], (unsigned long long)ray_iters_max);
+        if (lane == 0u)
         {
-            atomicAdd(&g_drain_prof[k], prof[k]);
+            for (int k = 0; k < 10; ++k)
+            {
+                atomicAdd(&g_drain_prof[k], prof[k]);
+            }
+            atomicMax(&g_drain_prof[10], prof[9]);
+            atomicMax(&g_drain_prof[11], __builtin_amdgcn_s_memtime() - t_begin);
         }
     }
     if (lane == 0u && wave_rays != 0u)

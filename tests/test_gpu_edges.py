@@ -306,3 +306,31 @@ def test_draw_frame_with_frames_in_flight_equals_immediate_dispatches(ctx):
     R.draw_frame(ctx, rr, cam_a)
     rr.close()
     dev.close()
+
+
+def test_non_finite_rays_hit_nothing_and_visit_nothing(ctx, oracle):
+    """A ray with a NaN or an infinity in its origin or direction (paths produce
+    them once in 10^8 samples) hits nothing by the definition of the triangle
+    test, in both scene kinds, and does not walk the tree: the box test's
+    hardware minima / maxima drop NaNs, so without a guard such a ray passes
+    every box and visits every node and triangle of the scene."""
+    sc = scenes.dragon_scene(nu=232, nv=117)
+    good = scenes.random_rays(64, seed=3)
+    bad = np.repeat(good[:1], 12, axis=0)
+    for k in range(6):
+        bad[k, k] = np.nan
+        bad[6 + k, k] = np.inf if k % 2 else -np.inf
+    orc = oracle.Scene(*sc.oracle_args())
+    for two_level in (False, True):
+        dev = R.DeviceScene(ctx, sc, two_level=two_level)
+        hits, st = dev.trace(bad, count=True)
+        assert np.all(hits["flat"] == R.NO_HIT)
+        assert st.nodes_visited == 0 and st.tris_tested == 0
+        ref, _ = orc.intersect(bad, use_bvh=False)
+        assert np.all(ref["id"] == oracle.NO_HIT)
+        # finite rays beside them are traced as ever
+        mixed = np.concatenate([bad[:3], good, bad[3:]])
+        h = dev.trace(mixed)
+        assert np.array_equal(h["flat"][3:3 + 64], dev.trace(good)["flat"])
+        assert (h["flat"][3:3 + 64] != R.NO_HIT).any()
+        dev.close()

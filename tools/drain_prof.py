@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
-"""where the persistent kernel's waves spend their cycles (PTC_DRAIN_PROFILE=1)."""
+"""Where the persistent kernel's waves spend their cycles (PTC_DRAIN_PROFILE=1).
+Usage: drain_prof.py [dragon | c5 | ref4] [dispatches in flight]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PTC_DRAIN_PROFILE"] = "1"
 import numpy as np, torch
 torch.cuda.is_available()
 from path_tracer_amd import renderer as R, scenes
-sc = scenes.dragon_scene(envmap=scenes.procedural_sky(2048, 1024))
+name = sys.argv[1] if len(sys.argv) > 1 else "dragon"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+sky = scenes.procedural_sky(2048, 1024)
+sc = {"dragon": lambda: scenes.dragon_scene(envmap=sky), "c5": lambda: scenes.dragon_in_cornell(sky),
+      "ref4": lambda: scenes.ref4_scene(scenes.knot_mesh(), sky)}[name]()
 ctx = R.create_context(0)
 w, h = 1920, 1080
 cam = R.default_camera(w, h)
 rr = R.create_render_resources(ctx, w, h, sc)
 rr.integrator, rr.accumulate = R.INTEGRATOR_WAVEFRONT, R.ACCUM_SUM
-rr.max_paths_in_flight = 256 * w * h
-rr.render(cam, frame=0, n_frames=256); ctx.synchronize()
+rr.max_paths_in_flight = spp * w * h
+print(name, "nodes", rr.scene.info.n_nodes, "depth", rr.scene.info.bvh_depth, "SAH", round(rr.scene.info.sah_cost, 2))
+rr.render(cam, frame=0, n_frames=spp); ctx.synchronize()
 out = (C.c_ulonglong * 16)()
 R.lib().ptc_debug_drain_profile(out)
 ctx.phase_times()
-rr.render(cam, frame=256, n_frames=256); ctx.synchronize()
+ctx.reset_stats()
+rr.render(cam, frame=spp, n_frames=spp); ctx.synchronize()
+st = ctx.stats()
+print("rays", st.rays, "paths", st.paths)
 R.lib().ptc_debug_drain_profile(out)
 p = np.array(out[:10], dtype=np.float64)
+print(f"most iterations of one wave {out[10]}, most cycles of one wave {out[11]:.3g}, most iterations of one ray {out[12]}")
 names = ["loop top / ballots", "shading (incl. park)", "pull", "start + pop", "node visit", "triangle tests (1-2)", "further triangle rounds"]
 tot = p[:7].sum()
 print("drain ms", ctx.phase_times()["drain"])
