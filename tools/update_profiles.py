@@ -55,8 +55,9 @@ for symbol, short in (("k_wf_drain", "drain"), ("k_wf_primary", "primary"), ("k_
         "ta_busy": round(k["TA_TA_BUSY_sum_per_dispatch"] / (a.cus * cycles), 4) if cycles else None,
         # active lanes per VALU instruction issued, of 64
         "lane_util": round(k["SQ_THREAD_CYCLES_VALU_per_dispatch"] / (64.0 * k["SQ_ACTIVE_INST_VALU_per_dispatch"]), 4),
-        # cycles a SIMD spends issuing VALU work, of the cycles the CUs' 4 SIMDs had
-        "valu_busy": round(k["SQ_ACTIVE_INST_VALU_per_dispatch"] / (4.0 * a.cus * cycles), 4) if cycles else None,
+        # VALU wave-instructions issued against what the CUs' 4 SIMDs can issue (a wave64 instruction takes a
+        # SIMD two cycles; quarter-rate instructions, which take longer, are counted as one like the rest)
+        "valu_busy": round(k["SQ_INSTS_VALU_per_dispatch"] * 2.0 / (4.0 * a.cus * cycles), 4) if cycles else None,
         "vmem_wave_insts_per_launch": k.get("SQ_INSTS_VMEM_RD_per_dispatch"),
         "method": "rocprofv3 --pmc, one pass per counter group (tools/profile_pmc.sh); FETCH_SIZE doubled (gfx950 "
                   "counts 128-B requests as 64 B; uncalibrated for scattered loads); FETCH/WRITE_SIZE sit on the "
