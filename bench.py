@@ -52,7 +52,7 @@ def parse_args():
                     help="dispatches per step over ALL GPUs (strong scaling: 4096 with --gpus 8 --steps 1 is the "
                          "headline configuration as written, 512 per GPU); overrides --spp-per-step")
     ap.add_argument("--max-paths", type=int, default=0,
-                    help="bound of the wavefront workspace in paths (about 160 B each); 0 = one step's worth")
+                    help="bound of the wavefront workspace in paths (76 B each, 156 with --wavefront-bounces); 0 = one step's worth")
     ap.add_argument("--scene", default="dragon",
                     help="dragon | ref4 | cornell | torus10m | c5 | dragon_small | path of an OBJ / PLY file")
     ap.add_argument("--width", type=int, default=1920)
@@ -212,9 +212,11 @@ def main():
     spp = parallel.split_spp(step_total, world)[rank]
     if step_total < world:
         raise SystemExit("bench.py: fewer dispatches per step than GPUs")
-    # workspace for a whole step in flight: 256 spp at 1080p are 2^29 paths, 85 GB of the 288 GB
-    # (bounded by half of the free device memory at about 170 B per path: larger steps run in several batches)
-    fits = int(torch.cuda.mem_get_info(local_rank)[0] * 0.5 / 170)
+    # workspace for a whole step in flight: 256 spp at 1080p are 2^29 paths, 40 GB of the 288 GB at 76 B per path
+    # (156 B when bounces run as launch pairs; bounded by half of the free device memory: larger steps run in
+    # several batches)
+    per_path = 160 if args.wavefront_bounces > 0 else 80
+    fits = int(torch.cuda.mem_get_info(local_rank)[0] * 0.5 / per_path)
     rr.max_paths_in_flight = min(args.max_paths or spp * W * H, fits, 2 ** 32 - 1)
     info = rr.scene.info
     integrator = {"megakernel": R.INTEGRATOR_MEGAKERNEL, "wavefront": R.INTEGRATOR_WAVEFRONT,
@@ -336,8 +338,8 @@ def main():
             "incoherent_mrays_s": rate(A["rays"] - F1["rays"], "drain"),
             "config": {"workload": f"{scene_desc}; {W}x{H}, {step_total} spp per step over {world} GPU(s) "
                                    f"({spp} per GPU, all in flight: workspace of {rr.max_paths_in_flight:,} paths = "
-                                   f"{rr.max_paths_in_flight * 160 / 1e9:.0f} GB set through max_paths_in_flight; "
-                                   f"the library's default of 2^27 paths would run 64 dispatches at a time), "
+                                   f"{rr.max_paths_in_flight * (per_path - 4) / 1e9:.0f} GB set through max_paths_in_flight; "
+                                   f"the library's default of 2^28 paths would run 128 dispatches at a time), "
                                    f"max depth {args.max_depth}, {args.integrator}"
                                    f"{', two-level scene' if args.two_level else ''}, spp sharded "
                                    f"over {world} GPU(s), RCCL sum at the end",

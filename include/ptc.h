@@ -222,10 +222,11 @@ typedef struct ptc_render_params
      * ptc_film_resolve(). */
     uint32_t tonemap;
     /* Wavefront / stream integrators: upper bound on the paths in flight, which
-     * sizes the per-context workspace (about 160 bytes per path with the
-     * wavefront integrator, 16 with the stream one). A call with more paths runs
-     * in several batches of whole dispatches. 0 = 2^27 (about 21 GB); at least
-     * one dispatch is always in flight. Does not change results. */
+     * sizes the per-context workspace (76 bytes per path with the wavefront
+     * integrator, 156 when wavefront_bounces > 0, 16 with the stream one). A call
+     * with more paths runs in several batches of whole dispatches. 0 = 2^28
+     * (about 20 GB: 128 dispatches of a 1920x1080 film); at least one dispatch is
+     * always in flight. Does not change results. */
     uint32_t max_paths_in_flight;
 } ptc_render_params;
 #define PTC_TONEMAP_PBR_NEUTRAL 0u
@@ -302,8 +303,9 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
  * context's hipMalloc'ed one, and the call creates no events (ptc_render_times
  * and ptc_phase_times do not see it). It calls no hipMalloc / hipFree and never
  * synchronises. Limit: one dispatch (width * height * samples_per_frame paths)
- * must fit the array — 156 bytes per path with the wavefront integrator (the
- * reference's default 640x480 film at one sample per frame fits), 16 with the
+ * must fit the array — 76 bytes per path with the wavefront integrator (880 k
+ * paths: the reference's default 640x480 film at one sample per frame fits
+ * twice over; 156 bytes per path when wavefront_bounces > 0), 16 with the
  * stream integrator (4 M paths); the megakernel uses no workspace. Beyond it:
  * PTC_E_LIMIT with the sizes in ptc_last_error(), nothing rendered. n_frames
  * beyond what fits run in several batches, as in ptc_render().

@@ -921,7 +921,7 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
     F.tonemap = params->tonemap;
     film->tonemap = params->tonemap;
     F.wavefront_bounces = params->wavefront_bounces;
-    F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : (1u << 27);
+    F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : (1u << 28);
     // one event pair per call, kept until ptc_render_times() collects them
     // (the static variant records none: creating events allocates)
     constexpr size_t kMaxTimed = 256;
@@ -1054,7 +1054,7 @@ int ptc_render_deferred(ptc_context *ctx, const ptc_scene *scene, ptc_film *film
     // as many dispatches as one batch of the queue-based integrators holds
     // (max_paths_in_flight); more would only wait for the next batch
     const uint64_t per_dispatch = (uint64_t)film->width * film->height * want.samples_per_frame;
-    const uint64_t budget = want.max_paths_in_flight ? want.max_paths_in_flight : (1u << 27);
+    const uint64_t budget = want.max_paths_in_flight ? want.max_paths_in_flight : (1u << 28);
     const uint64_t bound = std::max<uint64_t>(budget / std::max<uint64_t>(per_dispatch, 1u), 1u);
     if (pend.params.n_frames >= bound)
     {

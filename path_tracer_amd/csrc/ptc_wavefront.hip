@@ -34,9 +34,10 @@
 // Workspace of ptc_render_static(): callers that cannot allocate (code under
 // HIP graph capture, serving loops, harnesses that forbid hipMalloc) render
 // into this array instead of a hipMalloc'ed workspace. 64 MiB holds one
-// dispatch of the reference's default 640x480 film (src/application.cpp:206-207)
-// at one sample per frame with the wavefront integrator (156 bytes per path),
-// or 4 M paths with the stream integrator (16 bytes per path). Every GPU the
+// dispatch of up to 880 k paths with the wavefront integrator (76 bytes per
+// path; 156 when bounces run as launch pairs) -- twice the reference's default
+// 640x480 film (src/application.cpp:206-207) at one sample per frame -- or 4 M
+// paths with the stream integrator (16 bytes per path). Every GPU the
 // library runs on holds one copy from module load to process end; all calls on
 // a GPU share it, so calls that overlap on one GPU race.
 constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
@@ -966,12 +967,16 @@ void launch_drain(ptc_context *ctx, const ptc_scene *scene, const DFrame &F0, co
 
 // Workspace bytes of a batch of max_batch dispatches (the carving order of
 // launch_render_wavefront below).
-size_t workspace_bytes(size_t n_pixels, uint32_t spf, uint32_t max_batch, size_t n_counts, bool stream)
+// (pairs: bounces run as traversal / shading launch pairs, which take the second
+// queue and the hit records; the default, the persistent launch right after the
+// first bounce, needs one queue: 76 bytes per path instead of 156)
+size_t workspace_bytes(size_t n_pixels, uint32_t spf, uint32_t max_batch, size_t n_counts, bool stream, bool pairs)
 {
     const size_t cap = n_pixels * max_batch;
-    const size_t qcap = stream ? 1 : cap;
-    return 2 * (align256(qcap * 16) * 3 + align256(qcap * 8)) + align256(qcap * 16) + align256(qcap * 8) +
-           align256(cap * spf * 16) + align256(n_counts * 4) + align256(qcap * 4);
+    const size_t qcap = stream ? 1 : cap, pcap = pairs && !stream ? cap : 1;
+    return (align256(qcap * 16) * 3 + align256(qcap * 8)) + (align256(pcap * 16) * 3 + align256(pcap * 8)) +
+           align256(pcap * 16) + align256(pcap * 8) + align256(cap * spf * 16) + align256(n_counts * 4) +
+           align256(qcap * 4);
 }
 
 } // namespace
@@ -1006,7 +1011,8 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     const uint32_t spf = F0.samples_per_frame;
     const bool two_level = scene->d.inst_box != nullptr;
     const uint32_t wf_bounces = F0.wavefront_bounces;
-    // dispatches per batch: bounded so the workspace stays bounded (by default 2^27 paths, about 21 GB)
+    const bool pairs = wf_bounces > 0u && F0.max_depth > 1u; // some bounce runs as a traversal / shading launch pair
+    // dispatches per batch: bounded so the workspace stays bounded (by default 2^28 paths, about 20 GB)
     uint32_t max_batch = std::max<uint32_t>(
         1u, std::min<uint64_t>(F0.n_frames,
                                F0.max_paths_in_flight / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
@@ -1032,11 +1038,12 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             set_error("ptc_render_static: the static workspace was not set up on this device");
             return PTC_E_DEVICE;
         }
-        while (max_batch > 1u && workspace_bytes(n_pixels, spf, max_batch, n_counts, stream) > ctx->static_scratch_bytes)
+        while (max_batch > 1u &&
+               workspace_bytes(n_pixels, spf, max_batch, n_counts, stream, pairs) > ctx->static_scratch_bytes)
         {
             max_batch = max_batch / 2u;
         }
-        const size_t need = workspace_bytes(n_pixels, spf, max_batch, n_counts, stream);
+        const size_t need = workspace_bytes(n_pixels, spf, max_batch, n_counts, stream, pairs);
         if (need > ctx->static_scratch_bytes)
         {
             set_error("ptc_render_static: one dispatch of " + std::to_string(n_pixels) + " pixels x " +
@@ -1050,7 +1057,8 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
     // stream mode keeps live paths in registers: only the radiance array is needed
     const size_t qcap = stream ? 1 : cap;
-    const size_t bytes = workspace_bytes(n_pixels, spf, max_batch, n_counts, stream);
+    const size_t pcap = pairs && !stream ? cap : 1;
+    const size_t bytes = workspace_bytes(n_pixels, spf, max_batch, n_counts, stream, pairs);
     if (!static_scratch)
     {
         if (bytes > ctx->wf_bytes)
@@ -1071,15 +1079,17 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
         return r;
     };
     WfBuffers B;
-    for (int k = 0; k < 2; ++k)
+    // queue 1 is the one the primary pass fills; queue 0 and the hit records serve the launch pairs only
+    for (int k = 1; k >= 0; --k)
     {
-        B.q[k].a = reinterpret_cast<float4 *>(take(qcap * 16));
-        B.q[k].b = reinterpret_cast<float4 *>(take(qcap * 16));
-        B.q[k].c = reinterpret_cast<float4 *>(take(qcap * 16));
-        B.q[k].d = reinterpret_cast<float2 *>(take(qcap * 8));
+        const size_t c = k == 1 ? qcap : pcap;
+        B.q[k].a = reinterpret_cast<float4 *>(take(c * 16));
+        B.q[k].b = reinterpret_cast<float4 *>(take(c * 16));
+        B.q[k].c = reinterpret_cast<float4 *>(take(c * 16));
+        B.q[k].d = reinterpret_cast<float2 *>(take(c * 8));
     }
-    B.hit = reinterpret_cast<float4 *>(take(qcap * 16));
-    B.hit_ids = reinterpret_cast<uint2 *>(take(qcap * 8));
+    B.hit = reinterpret_cast<float4 *>(take(pcap * 16));
+    B.hit_ids = reinterpret_cast<uint2 *>(take(pcap * 8));
     B.radiance = reinterpret_cast<float4 *>(take(cap * spf * 16));
     B.counts = reinterpret_cast<uint32_t *>(take(n_counts * 4));
     uint32_t *carry = reinterpret_cast<uint32_t *>(take(qcap * 4));

@@ -488,7 +488,7 @@ class RenderResources:
         self.accumulate = ACCUM_RUNNING_MEAN
         self.instrument = False
         self.wavefront_bounces = 0  # 0 = library default
-        self.max_paths_in_flight = 0  # 0 = library default (2^27)
+        self.max_paths_in_flight = 0  # 0 = library default (2^28)
         self.tonemap = TONEMAP_PBR_NEUTRAL  # the one the reference compiles in (shader.rgen:218-219)
         # draw_frame() records its dispatch and returns, as the reference's does with its frames in flight
         # (src/renderer.hpp:208); False = every draw_frame() launches its own dispatch at once

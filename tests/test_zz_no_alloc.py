@@ -32,10 +32,10 @@ def _film(ctx, dev, w, h, integrator, static, frame, spf, n_frames, max_depth=8)
 def test_static_entry_point_equals_ptc_render_on_two_calls_in_a_row(ctx, integrator):
     sc = scenes.ref4_scene(scenes.knot_mesh(nu=96, nv=24), scenes.procedural_sky(64, 32))
     dev = R.DeviceScene(ctx, sc)
-    # first the reference's default film (640x480: one dispatch nearly fills the 64 MiB workspace,
-    # so the three dispatches run as three batches), then a smaller, odd-sized one
+    # first the reference's default film (640x480: two dispatches fit the 64 MiB workspace at 76 bytes per path,
+    # so the three dispatches run as two batches), then a smaller, odd-sized one
     for (w, h, spf, n_frames) in ((640, 480, 1, 3), (123, 77, 2, 5)):
-        if integrator in (R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_AUTO) and w * h * spf * 156 > (64 << 20):
+        if integrator in (R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_AUTO) and w * h * spf * 76 > (64 << 20):
             continue
         ref = _film(ctx, dev, w, h, integrator, False, frame=7, spf=spf, n_frames=n_frames)
         got = _film(ctx, dev, w, h, integrator, True, frame=7, spf=spf, n_frames=n_frames)
@@ -54,7 +54,7 @@ def test_static_entry_point_two_level_scene_and_limits(ctx):
             got = _film(ctx, dev, w, h, integrator, True, frame=0, spf=1, n_frames=20)
             assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32))
             assert np.array_equal(got[1], ref[1]) and got[2:] == ref[2:]
-    # beyond the limit: one 1080p dispatch needs 323 MB with the wavefront integrator
+    # beyond the limit: one 1080p dispatch needs 158 MB with the wavefront integrator
     w, h = 1920, 1080
     cam = R.default_camera(w, h)
     rr = R.RenderResources(ctx, w, h, dev)
