@@ -327,7 +327,9 @@ int ptc_render_static(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
  * ptc_film_flush(), ptc_synchronize() and ptc_get_stats() / ptc_render_times() /
  * ptc_phase_times(), before the scene is destroyed, and by everything that
  * reads or writes the film (read-backs, ptc_write_png, ptc_film_resolve,
- * ptc_render*, ptc_film_set_sample_count to another count); ptc_film_reset()
+ * ptc_render* -- ptc_render_static launches it through its own static
+ * workspace, so it still allocates nothing --, ptc_film_set_sample_count to
+ * another count); ptc_film_reset()
  * and ptc_film_destroy() drop it. ptc_film_sample_count() includes the
  * recorded samples. Not covered: a device pointer taken with
  * ptc_film_accum_device_ptr() or handed to ptc_film_create() is only current

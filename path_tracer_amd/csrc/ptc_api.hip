@@ -211,8 +211,9 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
                 const ptc_render_params *params, bool static_scratch);
 
 // Launches the dispatches a film has recorded (ptc_render_deferred) as one
-// ptc_render; nothing to do when there are none.
-int flush_film(ptc_film *film)
+// ptc_render; nothing to do when there are none. static_scratch: as one
+// ptc_render_static instead (the caller is one and must not allocate).
+int flush_film(ptc_film *film, bool static_scratch = false)
 {
     if (film->pending.params.n_frames == 0u)
     {
@@ -221,7 +222,7 @@ int flush_film(ptc_film *film)
     const ptc_film::Pending job = film->pending;
     film->pending.params.n_frames = 0u;
     film->pending.scene = nullptr;
-    return render_impl(film->ctx, job.scene, film, &job.camera, &job.params, false);
+    return render_impl(film->ctx, job.scene, film, &job.camera, &job.params, static_scratch);
 }
 
 // Every film of the context; with a scene given, only the films whose recorded
@@ -900,7 +901,7 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
         return PTC_E_DEVICE;
     }
     // dispatches recorded on this film come first (never the case when this is the flush itself)
-    if (const int rc = flush_film(film); rc != PTC_OK)
+    if (const int rc = flush_film(film, static_scratch); rc != PTC_OK)
     {
         return rc;
     }

@@ -90,3 +90,26 @@ def test_static_entry_point_creates_no_timing_records(ctx):
     assert ctx.render_times().size == 1
     rr.close()
     dev.close()
+
+
+def test_static_entry_point_launches_a_recorded_run_through_the_static_workspace(ctx):
+    """Dispatches recorded by ptc_render_deferred and not launched yet come first
+    when ptc_render_static is called on their film, through the static workspace
+    as well; the film equals the one of the same dispatches launched one by one."""
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(ctx, sc)
+    w, h = 96, 64
+    cam = R.default_camera(w, h)
+    films = []
+    for deferred in (False, True):
+        rr = R.RenderResources(ctx, w, h, dev)
+        rr.integrator, rr.max_depth = R.INTEGRATOR_WAVEFRONT, 6
+        for k in range(3):
+            rr.render(cam, frame=k, deferred=deferred)
+        assert rr.sample_count == 3
+        rr.render(cam, frame=3, n_frames=2, static=True)
+        assert rr.sample_count == 5
+        films.append(rr.read_accum())
+        rr.close()
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
+    dev.close()
