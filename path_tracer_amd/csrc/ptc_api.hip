@@ -241,6 +241,29 @@ int flush_context(ptc_context *ctx, const ptc_scene *only_scene = nullptr)
     return rc;
 }
 
+// Device staging memory of at least `bytes` for a query call; calls on one
+// context are ordered on its stream and end with a synchronisation, so one
+// buffer serves them all.
+int stage(ptc_context *ctx, size_t bytes, void **out)
+{
+    if (bytes > ctx->stage_bytes)
+    {
+        PTC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->stage_buf);
+        ctx->stage_buf = nullptr;
+        ctx->stage_bytes = 0;
+        if (hipMalloc(&ctx->stage_buf, bytes) != hipSuccess)
+        {
+            ctx->stage_buf = nullptr;
+            set_error("out of device memory for " + std::to_string(bytes) + " bytes of staging");
+            return PTC_E_NOMEM;
+        }
+        ctx->stage_bytes = bytes;
+    }
+    *out = ctx->stage_buf;
+    return PTC_OK;
+}
+
 uint32_t pending_samples(const ptc_film *film)
 {
     return film->pending.params.n_frames * film->pending.params.samples_per_frame;
@@ -327,6 +350,7 @@ void ptc_context_destroy(ptc_context *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->wf_buf);
+    (void)hipFree(ctx->stage_buf);
     (void)hipEventDestroy(ctx->ev_start);
     (void)hipEventDestroy(ctx->ev_stop);
     for (auto &p : ctx->ev_pool)
@@ -1094,9 +1118,13 @@ int ptc_primary_hits(ptc_context *ctx, const ptc_scene *scene, const ptc_camera 
     DFrame F = make_frame(*camera, width, height);
     F.global_frame_count = global_frame_count;
     F.tmax = tmax > 0.0f ? tmax : 10000.0f;
-    uint32_t *d_ids = nullptr;
+    void *mem = nullptr;
     const size_t n = (size_t)width * height;
-    PTC_HIP_CHECK(hipMalloc(&d_ids, n * 4));
+    if (const int rs = stage(ctx, n * 4, &mem); rs != PTC_OK)
+    {
+        return rs;
+    }
+    uint32_t *d_ids = static_cast<uint32_t *>(mem);
     int rc = launch_primary_hits(ctx, scene, F, d_ids);
     if (rc == PTC_OK)
     {
@@ -1111,7 +1139,6 @@ int ptc_primary_hits(ptc_context *ctx, const ptc_scene *scene, const ptc_camera 
             rc = PTC_E_DEVICE;
         }
     }
-    (void)hipFree(d_ids);
     return rc;
 }
 
@@ -1176,15 +1203,14 @@ int ptc_trace_rays(ptc_context *ctx, const ptc_scene *scene, const float *rays, 
     {
         return PTC_E_DEVICE;
     }
-    float *d_rays = nullptr;
-    ptc_hit *d_hits = nullptr;
-    PTC_HIP_CHECK(hipMalloc(&d_rays, n_rays * 24));
-    if (hipMalloc(&d_hits, n_rays * sizeof(ptc_hit)) != hipSuccess)
+    void *mem = nullptr;
+    const size_t rays_bytes = (n_rays * 24 + 255) & ~(size_t)255;
+    if (const int rs = stage(ctx, rays_bytes + n_rays * sizeof(ptc_hit), &mem); rs != PTC_OK)
     {
-        (void)hipFree(d_rays);
-        set_error("ptc_trace_rays: hipMalloc failed");
-        return PTC_E_NOMEM;
+        return rs;
     }
+    float *d_rays = static_cast<float *>(mem);
+    ptc_hit *d_hits = reinterpret_cast<ptc_hit *>(static_cast<char *>(mem) + rays_bytes);
     hipStream_t st = ctx->stream;
     int rc = PTC_OK;
     DeviceStats before{}, after{};
@@ -1210,8 +1236,6 @@ int ptc_trace_rays(ptc_context *ctx, const ptc_scene *scene, const float *rays, 
     {
         e = hipStreamSynchronize(st);
     }
-    (void)hipFree(d_rays);
-    (void)hipFree(d_hits);
     if (e != hipSuccess)
     {
         set_error(std::string("ptc_trace_rays: ") + hipGetErrorString(e));
@@ -1390,8 +1414,12 @@ int ptc_math_eval(ptc_context *ctx, int fn, const float *a, const float *b, floa
     {
         return PTC_E_DEVICE;
     }
-    float *d = nullptr;
-    PTC_HIP_CHECK(hipMalloc(&d, n * 16));
+    void *mem = nullptr;
+    if (const int rs = stage(ctx, n * 16, &mem); rs != PTC_OK)
+    {
+        return rs;
+    }
+    float *d = static_cast<float *>(mem);
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemcpyAsync(d, a, n * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
@@ -1415,7 +1443,6 @@ int ptc_math_eval(ptc_context *ctx, int fn, const float *a, const float *b, floa
     {
         e = hipStreamSynchronize(st);
     }
-    (void)hipFree(d);
     if (e != hipSuccess)
     {
         set_error(std::string("ptc_math_eval: ") + hipGetErrorString(e));

@@ -66,6 +66,10 @@ struct ptc_context
     // the library's static device array on this context's device (ptc_render_static)
     void *static_scratch = nullptr;
     size_t static_scratch_bytes = 0;
+    // staging memory of the query calls that take host pointers (ptc_primary_hits,
+    // ptc_trace_rays, ptc_math_eval): kept between calls, grown when a call needs more
+    void *stage_buf = nullptr;
+    size_t stage_bytes = 0;
     bool no_events = false; // set for the duration of a call that must not create events
     std::vector<ptc_film *> films; // films created on this context (they may hold recorded dispatches)
 };

@@ -16,7 +16,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptcore.so")
+# (PTC_LIBRARY names another build of the library: kernel experiments are measured side by side that way)
+LIB_PATH = os.environ.get("PTC_LIBRARY") or os.path.join(_HERE, "libptcore.so")
 
 KIND_DIFFUSE, KIND_SPECULAR, KIND_EMISSIVE, KIND_DIELECTRIC = 0, 1, 2, 3
 TONEMAP_PBR_NEUTRAL, TONEMAP_ACES = 0, 1
