@@ -547,6 +547,7 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
     PTC_TRY(hipMalloc(&S->d_positions, std::max<size_t>(nv, 1) * 12));
     PTC_TRY(hipMalloc(&S->d_normals, std::max<size_t>(nv, 1) * 12));
     PTC_TRY(hipMalloc(&S->d_indices, std::max<size_t>(nt, 1) * 12));
+    PTC_TRY(hipMalloc(&S->d_shade, std::max<size_t>(nt, 1) * 80));
     PTC_TRY(hipMalloc(&S->d_instances, std::max<size_t>(n_instances, 1) * sizeof(DInstance)));
     for (uint32_t m = 0; m < n_meshes; ++m)
     {
@@ -583,12 +584,18 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
     S->d.positions = S->d_positions;
     S->d.normals = S->d_normals;
     S->d.indices = S->d_indices;
+    S->d.shade = S->d_shade;
     S->d.instances = S->d_instances;
     S->d.n_instances = n_instances;
     S->d.n_tris = (uint32_t)total;
     S->info.n_triangles = (uint32_t)total;
     S->info.n_instances = n_instances;
 
+    rc = build_shade_records(ctx, S, vtx_off, tri_off);
+    if (rc != PTC_OK)
+    {
+        return fail(rc);
+    }
     BuildParams build_params;
     if (opts)
     {
@@ -638,7 +645,7 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
     }
     S->info.n_bvh_triangles = (uint32_t)(S->d_inst_box ? nt : total);
     S->info.device_bytes = (uint64_t)S->info.n_nodes * 80 + (uint64_t)(S->d_inst_box ? nt : total) * 48 + nv * 24 +
-                           nt * 12 + (S->d_inst_box ? n_instances * 32 : 0) +
+                           nt * (12 + 80) + (S->d_inst_box ? n_instances * 32 : 0) +
                            n_instances * sizeof(DInstance) +
                            (S->d_env ? (uint64_t)S->d.env_w * S->d.env_h * 16 : 0);
     *out = S;
@@ -659,6 +666,7 @@ void ptc_scene_destroy(ptc_scene *scene)
     (void)hipFree(scene->d_positions);
     (void)hipFree(scene->d_normals);
     (void)hipFree(scene->d_indices);
+    (void)hipFree(scene->d_shade);
     (void)hipFree(scene->d_instances);
     (void)hipFree(scene->d_inst_box);
     (void)hipFree(scene->d_env);

@@ -1385,7 +1385,62 @@ k_rebase_nodes(uint4 *__restrict__ nodes, uint32_t n_nodes, uint32_t node_off, u
         nodes[5u * (size_t)i + 1u] = w1;
     }
 }
+
+// One mesh: the positions and normals of each triangle's corners, as the 80-byte
+// record the hit shading reads (layout at DScene::shade).
+__global__ void __launch_bounds__(kBlock)
+k_shade_records(const float *__restrict__ positions, const float *__restrict__ normals,
+                const uint32_t *__restrict__ indices, uint32_t n_tris, float4 *__restrict__ out)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_tris)
+    {
+        return;
+    }
+    float w[20];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+    {
+        const size_t v = 3u * (size_t)indices[3u * (size_t)t + c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+        {
+            w[3 * c + k] = positions[v + k];
+            w[9 + 3 * c + k] = normals[v + k];
+        }
+    }
+    w[18] = w[19] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+    {
+        out[5u * (size_t)t + q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    }
+}
 } // namespace
+
+int build_shade_records(ptc_context *ctx, ptc_scene *scene, const std::vector<uint32_t> &vtx_off,
+                        const std::vector<uint32_t> &tri_off)
+{
+    const uint32_t n_meshes = (uint32_t)vtx_off.size() - 1u;
+    for (uint32_t m = 0; m < n_meshes; ++m)
+    {
+        const uint32_t n = tri_off[m + 1] - tri_off[m];
+        if (n == 0u)
+        {
+            continue;
+        }
+        k_shade_records<<<blocks_for(n), kBlock, 0, ctx->stream>>>(
+            scene->d_positions + 3u * (size_t)vtx_off[m], scene->d_normals + 3u * (size_t)vtx_off[m],
+            scene->d_indices + 3u * (size_t)tri_off[m], n, scene->d_shade + 5u * (size_t)tri_off[m]);
+    }
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess)
+    {
+        set_error(std::string("shade records: ") + hipGetErrorString(err));
+        return PTC_E_DEVICE;
+    }
+    return PTC_OK;
+}
 
 int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &instances,
                     const std::vector<uint32_t> &vtx_off, const std::vector<uint32_t> &tri_off,

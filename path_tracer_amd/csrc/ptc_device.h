@@ -33,6 +33,9 @@ struct DScene
     const float *__restrict__ positions; // 3 floats per vertex, all meshes
     const float *__restrict__ normals;
     const uint32_t *__restrict__ indices; // 3 per triangle, mesh-local vertex ids
+    // What shading a hit reads, gathered per mesh triangle: 5 x float4 = positions
+    // of the three corners (9 floats), their normals (9 floats), 2 unused.
+    const float4 *__restrict__ shade;
     const DInstance *__restrict__ instances;
     // Two-level scenes only (nullptr otherwise): a binary tree over the world
     // boxes of the instances, n_inst_nodes nodes in depth-first order, two
@@ -323,16 +326,15 @@ PTC_DEV Payload closest_hit(const DScene &S, vec3 ray_dir, const Hit &h, uint32_
         vtx_offset = I->vtx_offset;
         tri_offset = I->tri_offset;
     }
-    const uint32_t *__restrict__ idx = S.indices + 3u * (size_t)(tri_offset + h.primitive);
-    const uint32_t i0 = idx[0] + vtx_offset;
-    const uint32_t i1 = idx[1] + vtx_offset;
-    const uint32_t i2 = idx[2] + vtx_offset;
-    const vec3 v0 = load3(S.positions + 3u * (size_t)i0);
-    const vec3 v1 = load3(S.positions + 3u * (size_t)i1);
-    const vec3 v2 = load3(S.positions + 3u * (size_t)i2);
-    const vec3 n0 = load3(S.normals + 3u * (size_t)i0);
-    const vec3 n1 = load3(S.normals + 3u * (size_t)i1);
-    const vec3 n2 = load3(S.normals + 3u * (size_t)i2);
+    (void)vtx_offset;
+    const float4 *__restrict__ rec = S.shade + 5u * (size_t)(tri_offset + h.primitive);
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+    const vec3 v0 = v3(r0.x, r0.y, r0.z);
+    const vec3 v1 = v3(r0.w, r1.x, r1.y);
+    const vec3 v2 = v3(r1.z, r1.w, r2.x);
+    const vec3 n0 = v3(r2.y, r2.z, r2.w);
+    const vec3 n1 = v3(r3.x, r3.y, r3.z);
+    const vec3 n2 = v3(r3.w, r4.x, r4.y);
     const float bx = 1.0f - h.u - h.v, by = h.u, bz = h.v;
     const vec3 object_position = (v0 * bx + v1 * by) + v2 * bz;
     const vec3 object_normal = (n0 * bx + n1 * by) + n2 * bz;

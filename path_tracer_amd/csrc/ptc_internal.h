@@ -83,6 +83,7 @@ struct ptc_scene
     float *d_positions = nullptr;
     float *d_normals = nullptr;
     uint32_t *d_indices = nullptr;
+    float4 *d_shade = nullptr; // 5 x float4 per mesh triangle: its corners' positions and normals
     ptc::DInstance *d_instances = nullptr;
     float4 *d_inst_box = nullptr; // two-level scenes: (lo, hi) world box per instance
     float4 *d_env = nullptr;
@@ -163,6 +164,12 @@ struct BuildParams
 // d.nodes, d.tris and the BVH fields of scene->info.
 int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &instances,
               uint32_t n_flat_tris, const BuildParams &params);
+// Writes scene->d_shade from d_positions, d_normals and d_indices (all uploaded
+// already): per mesh triangle the object-space positions and normals of its three
+// corners, so that shading a hit takes one gather instead of the indices first and
+// the six vertex attributes after them.
+int build_shade_records(ptc_context *ctx, ptc_scene *scene, const std::vector<uint32_t> &vtx_off,
+                        const std::vector<uint32_t> &tri_off);
 // Two-level variant: one tree per mesh in object space (concatenated into
 // d_nodes / d_tris), instances[i].blas_root and the world boxes in d_inst_box.
 // mesh_box holds (lo.xyz, hi.xyz) of every mesh in object space.
