@@ -52,6 +52,8 @@ namespace
 {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kQueueSegments = 8u; // the chip's XCDs: workgroups are dealt to them round-robin
+constexpr uint32_t kFillStride = 64u;   // words between the segments' fill counts: one 256-byte line each
 
 struct WfState
 {
@@ -68,6 +70,14 @@ struct WfBuffers
     uint2 *hit_ids;   // instance, primitive
     float4 *radiance; // per path id: final radiance (w unused)
     uint32_t *counts; // counts[b] = live paths entering bounce b
+    // When the persistent launch follows the primary pass directly (seg_cap != 0),
+    // the queue the primary pass fills is cut into kQueueSegments segments of
+    // seg_cap slots: block i of the primary pass appends to segment
+    // i % kQueueSegments, whose fill count is fill[kFillStride * segment]. (One
+    // counter for all blocks bounds a pass in which most paths survive: the L2
+    // serialises same-address atomics at about 10 ns each.)
+    uint32_t *fill;
+    uint32_t seg_cap;
     // RNG state a finished path hands to the next sample of the same pixel and
     // dispatch (samples_per_frame > 1 continue one stream, shader.rgen:175-179);
     // nullptr when samples_per_frame == 1
@@ -236,7 +246,9 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
     if (threadIdx.x == 0u)
     {
         const uint32_t total = s_alive[0] + s_alive[1] + s_alive[2] + s_alive[3];
-        s_base = total != 0u ? atomicAdd(&B.counts[1], total) : 0u;
+        const uint32_t seg = blockIdx.x % kQueueSegments;
+        uint32_t *const counter = B.seg_cap != 0u ? B.fill + kFillStride * seg : &B.counts[1];
+        s_base = total != 0u ? seg * B.seg_cap + atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
     if (alive)
@@ -457,7 +469,10 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     const WfState qi = B.q[src];
     const uint32_t max_depth = F.max_depth;
     const float tmax = F.tmax;
-    const uint32_t n = kCamera ? n_items : B.counts[bounce0];
+    // queue-fed: the primary pass filled the queue by segments (B.seg_cap slots
+    // each, B.fill[] used), or the queue is one run of B.counts[bounce0] items
+    const bool by_fill = !kCamera && B.seg_cap != 0u;
+    const uint32_t n = kCamera ? n_items : (by_fill ? kQueueSegments * B.seg_cap : B.counts[bounce0]);
     const uint32_t lane = lane_id();
     // Lane state machine. A lane is idle (kIdle), walking the tree for its
     // path's current ray (kTrav), or has its closest hit and waits to be shaded
@@ -479,8 +494,8 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // atomics each (the Cornell box, where every path survives and pulls are
     // frequent, gains 16 %), and one L2 serves paths from one part of the
     // picture (no measurable effect on the 871k-triangle scene).
-    constexpr uint32_t kSegments = 8u;
-    const uint32_t seg_len = ((n + kSegments * kChunk - 1u) / (kSegments * kChunk)) * kChunk;
+    constexpr uint32_t kSegments = kQueueSegments;
+    const uint32_t seg_len = by_fill ? B.seg_cap : ((n + kSegments * kChunk - 1u) / (kSegments * kChunk)) * kChunk;
     uint32_t seg = blockIdx.x % kSegments, segs_left = kSegments;
     bool queue_done = n == 0u;                // nothing left to reserve beyond chunk_end
     bool exhausted = n == 0u;
@@ -663,7 +678,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 }
                 fresh = __shfl(fresh, (int)leader, 64);
                 const uint32_t lo = seg * seg_len;
-                const uint32_t hi = lo + seg_len < n ? lo + seg_len : n;
+                const uint32_t hi = by_fill ? lo + B.fill[kFillStride * seg] : (lo + seg_len < n ? lo + seg_len : n);
                 if (lo < hi && fresh < hi - lo)
                 {
                     chunk_next = lo + fresh;
@@ -965,18 +980,87 @@ void launch_drain(ptc_context *ctx, const ptc_scene *scene, const DFrame &F0, co
     }
 }
 
+// Blocks of the primary pass over nb dispatches of a width x height film, and the
+// lanes per pixel (as a power of two) its pixel-major form uses: 64, 32 or 16,
+// whichever leaves the fewest lanes without a dispatch (ties go to the wider
+// one); below 16 dispatches a wave is an 8x8 pixel tile of one dispatch.
+uint64_t primary_grid(uint32_t width, uint32_t height, uint32_t nb, uint32_t *lane_bits_out)
+{
+    // whole 8x8 groups of 16x16-pixel tiles
+    const uint64_t tiles = (uint64_t)((width + 127u) >> 7) * ((height + 127u) >> 7) * 64u;
+    if (nb < 16u)
+    {
+        *lane_bits_out = 0u;
+        return tiles * nb;
+    }
+    uint32_t lane_bits = 0, best_waste = ~0u;
+    for (uint32_t bits = 6; bits >= 4; --bits)
+    {
+        const uint32_t groups = (nb + (1u << bits) - 1u) >> bits;
+        const uint32_t waste = (groups << bits) - nb;
+        if (waste < best_waste)
+        {
+            best_waste = waste;
+            lane_bits = bits;
+        }
+    }
+    *lane_bits_out = lane_bits;
+    const uint64_t pixel_blocks = (tiles * 256u) / ((uint32_t)kBlock >> lane_bits);
+    const uint32_t k_groups = (nb + (1u << lane_bits) - 1u) >> lane_bits;
+    return pixel_blocks * k_groups;
+}
+
+// Slots per queue segment for a primary pass of `grid` blocks: every block may
+// append all of its kBlock paths, and segment s takes the blocks i with
+// i % kQueueSegments == s.
+uint64_t segment_slots(uint64_t grid)
+{
+    return ((grid + kQueueSegments - 1u) / kQueueSegments) * (uint64_t)kBlock;
+}
+
+// Words of the counter block: live paths per bounce, the persistent launch's
+// queue heads, then (from a multiple of kFillStride on) the segments' fill counts.
+size_t fill_offset(uint32_t max_depth)
+{
+    return (((size_t)max_depth + 1 + kQueueSegments + kFillStride - 1) / kFillStride) * kFillStride;
+}
+size_t counter_words(uint32_t max_depth)
+{
+    return fill_offset(max_depth) + (size_t)kQueueSegments * kFillStride;
+}
+
+// Slots of the queue the primary pass fills, for batches of max_batch dispatches:
+// none with the stream integrator (live paths stay in registers), one per path
+// when bounces run as launch pairs (one run of items behind one counter), else
+// the segments' capacities (the film rounded up to the primary pass's blocks).
+size_t queue_slots(uint32_t width, uint32_t height, uint32_t max_batch, bool stream, bool pairs)
+{
+    if (stream)
+    {
+        return 1;
+    }
+    if (pairs)
+    {
+        return (size_t)width * height * max_batch;
+    }
+    uint32_t bits;
+    return (size_t)kQueueSegments * segment_slots(primary_grid(width, height, max_batch, &bits));
+}
+
 // Workspace bytes of a batch of max_batch dispatches (the carving order of
 // launch_render_wavefront below).
 // (pairs: bounces run as traversal / shading launch pairs, which take the second
 // queue and the hit records; the default, the persistent launch right after the
-// first bounce, needs one queue: 76 bytes per path instead of 156)
-size_t workspace_bytes(size_t n_pixels, uint32_t spf, uint32_t max_batch, size_t n_counts, bool stream, bool pairs)
+// first bounce, needs one queue: 76 bytes per path instead of 156, a little more
+// where the film is not whole 128x128-pixel groups)
+size_t workspace_bytes(uint32_t width, uint32_t height, uint32_t spf, uint32_t max_batch, uint32_t max_depth,
+                       bool stream, bool pairs)
 {
-    const size_t cap = n_pixels * max_batch;
-    const size_t qcap = stream ? 1 : cap, pcap = pairs && !stream ? cap : 1;
+    const size_t cap = (size_t)width * height * max_batch;
+    const size_t qcap = queue_slots(width, height, max_batch, stream, pairs), pcap = pairs && !stream ? cap : 1;
     return (align256(qcap * 16) * 3 + align256(qcap * 8)) + (align256(pcap * 16) * 3 + align256(pcap * 8)) +
-           align256(pcap * 16) + align256(pcap * 8) + align256(cap * spf * 16) + align256(n_counts * 4) +
-           align256(qcap * 4);
+           align256(pcap * 16) + align256(pcap * 8) + align256(cap * spf * 16) +
+           align256(counter_words(max_depth) * 4) + align256(qcap * 4);
 }
 
 } // namespace
@@ -1028,7 +1112,28 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
         }
         max_batch = (uint32_t)std::min<uint64_t>(max_batch, fit);
     }
-    const size_t n_counts = (size_t)F0.max_depth + 1 + 8; // live paths per bounce, then the drain's queue heads
+    // The queue's segments are sized by the blocks of the primary pass, which cover
+    // the film rounded up to whole 128x128-pixel groups: for a film much smaller
+    // than its groups the batch shrinks so that the queue has at most twice the
+    // slots max_paths_in_flight asks for (and fewer than 2^32: slots are 32-bit).
+    if (!stream && !pairs)
+    {
+        const uint64_t bound = std::min<uint64_t>(
+            0xffffffffull, 2u * std::max<uint64_t>(F0.max_paths_in_flight, (uint64_t)n_pixels * spf));
+        while (max_batch > 1u && queue_slots(F0.width, F0.height, max_batch, stream, pairs) > bound)
+        {
+            max_batch = max_batch / 2u;
+        }
+        if (queue_slots(F0.width, F0.height, max_batch, stream, pairs) > 0xffffffffull)
+        {
+            set_error("ptc_render: the film rounded up to 128x128-pixel groups exceeds 2^32 paths per dispatch");
+            return PTC_E_LIMIT;
+        }
+    }
+    const size_t n_counts = counter_words(F0.max_depth);
+    auto bytes_for = [&](uint32_t batch) {
+        return workspace_bytes(F0.width, F0.height, spf, batch, F0.max_depth, stream, pairs);
+    };
     char *workspace = nullptr;
     if (static_scratch)
     {
@@ -1038,12 +1143,11 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             set_error("ptc_render_static: the static workspace was not set up on this device");
             return PTC_E_DEVICE;
         }
-        while (max_batch > 1u &&
-               workspace_bytes(n_pixels, spf, max_batch, n_counts, stream, pairs) > ctx->static_scratch_bytes)
+        while (max_batch > 1u && bytes_for(max_batch) > ctx->static_scratch_bytes)
         {
             max_batch = max_batch / 2u;
         }
-        const size_t need = workspace_bytes(n_pixels, spf, max_batch, n_counts, stream, pairs);
+        const size_t need = bytes_for(max_batch);
         if (need > ctx->static_scratch_bytes)
         {
             set_error("ptc_render_static: one dispatch of " + std::to_string(n_pixels) + " pixels x " +
@@ -1056,9 +1160,9 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     }
     const size_t cap = (size_t)n_pixels * max_batch; // live paths of one pass
     // stream mode keeps live paths in registers: only the radiance array is needed
-    const size_t qcap = stream ? 1 : cap;
+    const size_t qcap = queue_slots(F0.width, F0.height, max_batch, stream, pairs);
     const size_t pcap = pairs && !stream ? cap : 1;
-    const size_t bytes = workspace_bytes(n_pixels, spf, max_batch, n_counts, stream, pairs);
+    const size_t bytes = bytes_for(max_batch);
     if (!static_scratch)
     {
         if (bytes > ctx->wf_bytes)
@@ -1092,13 +1196,13 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     B.hit_ids = reinterpret_cast<uint2 *>(take(pcap * 8));
     B.radiance = reinterpret_cast<float4 *>(take(cap * spf * 16));
     B.counts = reinterpret_cast<uint32_t *>(take(n_counts * 4));
+    B.fill = B.counts + fill_offset(F0.max_depth);
+    B.seg_cap = 0u;
     uint32_t *carry = reinterpret_cast<uint32_t *>(take(qcap * 4));
     B.carry = spf > 1u && !stream ? carry : nullptr;
     B.spf = spf;
     B.n_pixels = n_pixels;
 
-    // primary-pass tiles: whole 8x8 groups of 16x16-pixel tiles
-    const uint32_t tiles = ((F0.width + 127u) >> 7) * ((F0.height + 127u) >> 7) * 64u;
     const uint32_t persistent_blocks = (uint32_t)ctx->n_cus * 6u;
     uint32_t sample_count = F0.sample_count;
     for (uint32_t k0 = 0; k0 < F0.n_frames; k0 += max_batch)
@@ -1122,57 +1226,35 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             PTC_HIP_CHECK(hipMemsetAsync(B.counts, 0, n_counts * 4, st));
             {
                 PhaseTimer timer(ctx, PTC_PHASE_PRIMARY);
-                // lanes per pixel: 64, 32 or 16, whichever leaves the fewest lanes
-                // without a dispatch (ties go to the wider one)
-                uint32_t lane_bits = 0, best_waste = ~0u;
-                for (uint32_t bits = 6; bits >= 4; --bits)
-                {
-                    const uint32_t groups = (nb + (1u << bits) - 1u) >> bits;
-                    const uint32_t waste = (groups << bits) - nb;
-                    if (waste < best_waste)
-                    {
-                        best_waste = waste;
-                        lane_bits = bits;
-                    }
-                }
+                uint32_t lane_bits = 0;
+                const uint32_t grid = (uint32_t)primary_grid(F0.width, F0.height, nb, &lane_bits);
+                B.seg_cap = pairs ? 0u : (uint32_t)segment_slots(grid);
                 // kernel variant by (pixel-major mapping, two-level scene, counting)
-                auto launch = [&](auto kernel, uint32_t grid, uint32_t bits) {
-                    kernel<<<grid, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0, s, nb, bits, ctx->d_stats);
+                auto launch = [&](auto kernel) {
+                    kernel<<<grid, kBlock, 0, st>>>(scene->d, F0, B, F0.global_frame_count, k0, s, nb, lane_bits, ctx->d_stats);
                 };
                 if (nb >= 16u)
                 {
-                    const uint32_t pixel_blocks = (tiles * 256u) / (kBlock >> lane_bits);
-                    const uint32_t k_groups = (nb + (1u << lane_bits) - 1u) >> lane_bits;
-                    const uint32_t grid = pixel_blocks * k_groups;
                     if (count)
                     {
-                        two_level ? launch(k_wf_primary<1, true, true>, grid, lane_bits)
-                                  : launch(k_wf_primary<1, false, true>, grid, lane_bits);
+                        two_level ? launch(k_wf_primary<1, true, true>) : launch(k_wf_primary<1, false, true>);
                     }
                     else if (lane_bits == 6u)
                     {
-                        two_level ? launch(k_wf_primary<2, true, false>, grid, lane_bits)
-                                  : launch(k_wf_primary<2, false, false>, grid, lane_bits);
+                        two_level ? launch(k_wf_primary<2, true, false>) : launch(k_wf_primary<2, false, false>);
                     }
                     else
                     {
-                        two_level ? launch(k_wf_primary<1, true, false>, grid, lane_bits)
-                                  : launch(k_wf_primary<1, false, false>, grid, lane_bits);
+                        two_level ? launch(k_wf_primary<1, true, false>) : launch(k_wf_primary<1, false, false>);
                     }
+                }
+                else if (count)
+                {
+                    two_level ? launch(k_wf_primary<0, true, true>) : launch(k_wf_primary<0, false, true>);
                 }
                 else
                 {
-                    const uint32_t grid = tiles * nb;
-                    if (count)
-                    {
-                        two_level ? launch(k_wf_primary<0, true, true>, grid, 0u)
-                                  : launch(k_wf_primary<0, false, true>, grid, 0u);
-                    }
-                    else
-                    {
-                        two_level ? launch(k_wf_primary<0, true, false>, grid, 0u)
-                                  : launch(k_wf_primary<0, false, false>, grid, 0u);
-                    }
+                    two_level ? launch(k_wf_primary<0, true, false>) : launch(k_wf_primary<0, false, false>);
                 }
             }
             const uint32_t blocks = std::min<uint32_t>(persistent_blocks, (n_paths + kBlock - 1) / kBlock);
