@@ -32,10 +32,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # Algorithmic bytes: 80 B per wide node fetched (a fetch shared by the lanes of a
-# wave counts once), 48 B per triangle tested, 84 B per shaded hit (3 indices +
-# 3 positions + 3 normals), 64 B per escaped path (4 RGBA32F texels), 36 B per
+# wave counts once), 48 B per triangle tested, 80 B per shaded hit (the triangle's
+# shading record), 64 B per escaped path (4 RGBA32F texels), 36 B per
 # pixel per dispatch (accumulator read + write, RGBA8 write).
-B_NODE, B_TRI, B_HIT, B_MISS, B_PIXEL = 80, 48, 84, 64, 36
+B_NODE, B_TRI, B_HIT, B_MISS, B_PIXEL = 80, 48, 80, 64, 36
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth of the 8 XCDs
 
@@ -303,13 +303,13 @@ def main():
         node_fetches = lambda c: c["nodes"] - c["uniform_nodes"] + c["uniform_fetches"]
         if dom == "drain":
             # bounces >= 1 only: the rays, nodes and triangles beyond the first bounce; every such ray ends in
-            # a shaded hit (84 B gather) or a sky lookup (64 B, billed as 84)
+            # a sky lookup (64 B) or a shaded hit (80 B gather, billed as 64)
             rays_d, nodes_d, tris_d = A["rays"] - F1["rays"], A["nodes"] - F1["nodes"], A["tris"] - F1["tris"]
             fetches_d = nodes_d
-            alg_bytes = fetches_d * B_NODE + tris_d * B_TRI + rays_d * B_HIT
+            alg_bytes = fetches_d * B_NODE + tris_d * B_TRI + rays_d * B_MISS
         elif dom == "primary":
             rays_d, nodes_d, tris_d, fetches_d = P["rays"], P["nodes"], P["tris"], node_fetches(P)
-            # every camera path ends its first bounce in a sky lookup (64 B) or a hit gather (84 B, billed as 64)
+            # every camera path ends its first bounce in a sky lookup (64 B) or a hit gather (80 B, billed as 64)
             # and stores its radiance (16 B) or its queue entry (56 B, billed as 16)
             alg_bytes = fetches_d * B_NODE + tris_d * B_TRI + P["paths"] * (B_MISS + 16)
         else:

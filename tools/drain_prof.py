@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the persistent kernel's waves spend their cycles (PTC_DRAIN_PROFILE=1).
-Usage: drain_prof.py [dragon | c5 | ref4] [dispatches in flight]"""
+Usage: drain_prof.py [dragon | c5 | ref4 | cornell] [dispatches in flight] [width height max_depth]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PTC_DRAIN_PROFILE"] = "1"
@@ -11,12 +11,14 @@ name = sys.argv[1] if len(sys.argv) > 1 else "dragon"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 sky = scenes.procedural_sky(2048, 1024)
 sc = {"dragon": lambda: scenes.dragon_scene(envmap=sky), "c5": lambda: scenes.dragon_in_cornell(sky),
-      "ref4": lambda: scenes.ref4_scene(scenes.knot_mesh(), sky)}[name]()
+      "ref4": lambda: scenes.ref4_scene(scenes.knot_mesh(), sky), "cornell": scenes.cornell_box}[name]()
 ctx = R.create_context(0)
-w, h = 1920, 1080
+w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
 cam = R.default_camera(w, h)
 rr = R.create_render_resources(ctx, w, h, sc)
 rr.integrator, rr.accumulate = R.INTEGRATOR_WAVEFRONT, R.ACCUM_SUM
+if len(sys.argv) > 5:
+    rr.max_depth = int(sys.argv[5])
 rr.max_paths_in_flight = spp * w * h
 print(name, "nodes", rr.scene.info.n_nodes, "depth", rr.scene.info.bvh_depth, "SAH", round(rr.scene.info.sah_cost, 2))
 rr.render(cam, frame=0, n_frames=spp); ctx.synchronize()
