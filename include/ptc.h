@@ -224,7 +224,7 @@ typedef struct ptc_render_params
     /* Wavefront / stream integrators: upper bound on the paths in flight, which
      * sizes the per-context workspace (76 bytes per path with the wavefront
      * integrator, 60 of them per pixel of the film rounded up to whole
-     * 128x128-pixel groups; 156 when wavefront_bounces > 0, 16 with the stream
+     * 32x32-pixel groups; 156 when wavefront_bounces > 0, 16 with the stream
      * one). A call
      * with more paths runs in several batches of whole dispatches. 0 = 2^28
      * (about 20 GB: 128 dispatches of a 1920x1080 film); at least one dispatch is
@@ -306,7 +306,7 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
  * and ptc_phase_times do not see it). It calls no hipMalloc / hipFree and never
  * synchronises. Limit: one dispatch (width * height * samples_per_frame paths)
  * must fit the array — 76 bytes per path with the wavefront integrator, 60 of
- * them per pixel of the film rounded up to whole 128x128-pixel groups (880 k
+ * them per pixel of the film rounded up to whole 32x32-pixel groups (880 k
  * paths: the reference's default 640x480 film at one sample per frame fits
  * twice over; 156 bytes per path when wavefront_bounces > 0), 16 with the
  * stream integrator (4 M paths); the megakernel uses no workspace. Beyond it:

@@ -54,6 +54,10 @@ namespace
 constexpr int kBlock = 256;
 constexpr uint32_t kQueueSegments = 8u; // the chip's XCDs: workgroups are dealt to them round-robin
 constexpr uint32_t kFillStride = 64u;   // words between the segments' fill counts: one 256-byte line each
+// The primary pass walks the film in square groups of 2x2 tiles of 16x16 pixels, groups row by row, the tiles
+// of a group and the pixels of a tile along a Z-order curve. (Groups of 4x4 and 8x8 tiles run at the same
+// rate; the smallest leaves the fewest blocks beyond the film's edge: a 1080p film is covered as 1920x1088.)
+constexpr uint32_t kGroupBits = 1u, kGroupTiles = 1u << kGroupBits, kGroupPixels = 16u << kGroupBits;
 
 struct WfState
 {
@@ -152,7 +156,7 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
     __shared__ uint2 s_stack[kPrimaryLds * kBlock];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tiles_x = (F.width + 15u) >> 4;
-    const uint32_t groups_x = (tiles_x + 7u) >> 3;
+    const uint32_t groups_x = (tiles_x + kGroupTiles - 1u) >> kGroupBits;
     uint32_t px, py, k;
     bool inside;
     constexpr bool kPixelMajor = kMapping != 0;
@@ -177,9 +181,9 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
         }
         k = (blockIdx.x % k_groups) * lanes_per_pixel + (threadIdx.x & (lanes_per_pixel - 1u));
         const uint32_t tile = q >> 8, l = q & 255u;
-        const uint32_t group = tile >> 6, m = tile & 63u;
-        const uint32_t bx = (group % groups_x) * 8u + ((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u));
-        const uint32_t by = (group / groups_x) * 8u + (((m >> 1) & 1u) | ((m >> 2) & 2u) | ((m >> 3) & 4u));
+        const uint32_t group = tile >> (2u * kGroupBits), m = tile & (kGroupTiles * kGroupTiles - 1u);
+        const uint32_t bx = (group % groups_x) * kGroupTiles + ((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u));
+        const uint32_t by = (group / groups_x) * kGroupTiles + (((m >> 1) & 1u) | ((m >> 2) & 2u) | ((m >> 3) & 4u));
         px = bx * 16u + ((l & 1u) | ((l >> 1) & 2u) | ((l >> 2) & 4u) | ((l >> 3) & 8u));
         py = by * 16u + (((l >> 1) & 1u) | ((l >> 2) & 2u) | ((l >> 3) & 4u) | ((l >> 4) & 8u));
         inside = px < F.width && py < F.height && k < n_disp;
@@ -190,12 +194,12 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
         // dispatches of one tile, so the blocks resident at any time (and the
         // queue they fill) stay within a few tiles' geometry, and those tiles
         // form a compact patch: tiles are numbered along a Z-order curve inside
-        // 8x8-tile groups.
+        // their groups.
         const uint32_t tile = blockIdx.x / n_disp;
         k = blockIdx.x % n_disp; // dispatch within this batch
-        const uint32_t group = tile >> 6, m = tile & 63u;
-        const uint32_t bx = (group % groups_x) * 8u + ((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u));
-        const uint32_t by = (group / groups_x) * 8u + (((m >> 1) & 1u) | ((m >> 2) & 2u) | ((m >> 3) & 4u));
+        const uint32_t group = tile >> (2u * kGroupBits), m = tile & (kGroupTiles * kGroupTiles - 1u);
+        const uint32_t bx = (group % groups_x) * kGroupTiles + ((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u));
+        const uint32_t by = (group / groups_x) * kGroupTiles + (((m >> 1) & 1u) | ((m >> 2) & 2u) | ((m >> 3) & 4u));
         px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
         py = by * 16u + (wave >> 1) * 8u + (lane >> 3);
         inside = px < F.width && py < F.height; // false for all lanes of tiles past the edge
@@ -986,8 +990,9 @@ void launch_drain(ptc_context *ctx, const ptc_scene *scene, const DFrame &F0, co
 // one); below 16 dispatches a wave is an 8x8 pixel tile of one dispatch.
 uint64_t primary_grid(uint32_t width, uint32_t height, uint32_t nb, uint32_t *lane_bits_out)
 {
-    // whole 8x8 groups of 16x16-pixel tiles
-    const uint64_t tiles = (uint64_t)((width + 127u) >> 7) * ((height + 127u) >> 7) * 64u;
+    // whole groups of 16x16-pixel tiles
+    const uint64_t tiles = (uint64_t)((width + kGroupPixels - 1u) / kGroupPixels) * ((height + kGroupPixels - 1u) / kGroupPixels) *
+                           (kGroupTiles * kGroupTiles);
     if (nb < 16u)
     {
         *lane_bits_out = 0u;
@@ -1052,7 +1057,7 @@ size_t queue_slots(uint32_t width, uint32_t height, uint32_t max_batch, bool str
 // (pairs: bounces run as traversal / shading launch pairs, which take the second
 // queue and the hit records; the default, the persistent launch right after the
 // first bounce, needs one queue: 76 bytes per path instead of 156, a little more
-// where the film is not whole 128x128-pixel groups)
+// where the film is not whole 32x32-pixel groups)
 size_t workspace_bytes(uint32_t width, uint32_t height, uint32_t spf, uint32_t max_batch, uint32_t max_depth,
                        bool stream, bool pairs)
 {
@@ -1113,7 +1118,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
         max_batch = (uint32_t)std::min<uint64_t>(max_batch, fit);
     }
     // The queue's segments are sized by the blocks of the primary pass, which cover
-    // the film rounded up to whole 128x128-pixel groups: for a film much smaller
+    // the film rounded up to whole 32x32-pixel groups: for a film much smaller
     // than its groups the batch shrinks so that the queue has at most twice the
     // slots max_paths_in_flight asks for (and fewer than 2^32: slots are 32-bit).
     if (!stream && !pairs)
@@ -1126,7 +1131,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
         }
         if (queue_slots(F0.width, F0.height, max_batch, stream, pairs) > 0xffffffffull)
         {
-            set_error("ptc_render: the film rounded up to 128x128-pixel groups exceeds 2^32 paths per dispatch");
+            set_error("ptc_render: the film rounded up to 32x32-pixel groups exceeds 2^32 paths per dispatch");
             return PTC_E_LIMIT;
         }
     }

@@ -86,7 +86,9 @@ def test_workspace_bound_splits_a_call_into_batches(ctx, oracle, spf):
     partial, same film."""
     w, h, n_frames = 20, 12, 37
     _render_all(ctx, oracle, scenes.cornell_box(tall_kind=1), w, h, n_frames=n_frames, max_depth=5, spf=spf,
-                max_paths_in_flight=w * h * spf * 16 + 7)   # 16 dispatches per batch -> 16 + 16 + 5
+                max_paths_in_flight=w * h * spf * 16 + 7)   # 16 dispatches per batch at most (fewer where the queue,
+                                                            # which covers whole 32x32-pixel groups, would exceed
+                                                            # twice the bound): several batches, the last one partial
     _render_all(ctx, oracle, scenes.cornell_box(tall_kind=1), w, h, n_frames=5, max_depth=5, spf=spf,
                 max_paths_in_flight=1)                      # one dispatch at a time
 
