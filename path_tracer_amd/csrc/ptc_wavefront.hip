@@ -561,6 +561,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long t_begin = t_prev;
+    unsigned long long t_exhausted = 0ull; // kProfile: when the wave found the queue empty
     uint32_t ray_iters = 0u, ray_iters_max = 0u; // kProfile: loop iterations of the lane's current ray, and the most any of its rays took
 #define PTC_PROF(k)                                                     \
     if (kProfile)                                                       \
@@ -730,6 +731,10 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             }
             start = start || got;
             exhausted = queue_done && chunk_next == chunk_end; // wave-uniform
+            if (kProfile && exhausted && t_exhausted == 0ull)
+            {
+                t_exhausted = __builtin_amdgcn_s_memtime();
+            }
         }
         PTC_PROF(2)
         wave_rays += (uint32_t)__builtin_popcountll(__ballot(start));
@@ -877,7 +882,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
 #undef PTC_WORD
     if (kProfile)
     {
-        // 10: most iterations of one wave; 11: most cycles of one wave; 12: most iterations of one ray
+        // 10: most iterations of one wave; 11: most cycles of one wave; 12: most iterations of one ray;
         atomicMax(&g_drain_prof[12], (unsigned long long)ray_iters_max);
         if (lane == 0u)
         {
@@ -885,8 +890,13 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             {
                 atomicAdd(&g_drain_prof[k], prof[k]);
             }
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
             atomicMax(&g_drain_prof[10], prof[9]);
-            atomicMax(&g_drain_prof[11], __builtin_amdgcn_s_memtime() - t_begin);
+            atomicMax(&g_drain_prof[11], t_end - t_begin);
+            // 13: cycles all waves lived; 14: waves; 15: cycles they lived after the queue had nothing left for them
+            atomicAdd(&g_drain_prof[13], t_end - t_begin);
+            atomicAdd(&g_drain_prof[14], 1ull);
+            atomicAdd(&g_drain_prof[15], t_end - (t_exhausted != 0ull ? t_exhausted : t_end));
         }
     }
     if (lane == 0u && wave_rays != 0u)

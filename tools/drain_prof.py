@@ -32,6 +32,9 @@ print("rays", st.rays, "paths", st.paths)
 R.lib().ptc_debug_drain_profile(out)
 p = np.array(out[:10], dtype=np.float64)
 print(f"most iterations of one wave {out[10]}, most cycles of one wave {out[11]:.3g}, most iterations of one ray {out[12]}")
+if out[14]:
+    print(f"waves {out[14]}: mean life {out[13] / out[14] / out[11]:.3f} of the longest; after the queue ran dry for them "
+          f"{out[15] / out[14] / out[11]:.3f} of the longest life on average")
 names = ["loop top / ballots", "shading (incl. park)", "pull", "start + pop", "node visit", "triangle tests (1-2)", "further triangle rounds"]
 tot = p[:7].sum()
 print("drain ms", ctx.phase_times()["drain"])
