@@ -293,11 +293,11 @@ PTC_DEV vec3 load3(const float *__restrict__ p)
 // selected by the instance's kind (the SBT record offset).
 PTC_DEV Payload closest_hit(const DScene &S, vec3 ray_dir, const Hit &h, uint32_t rng)
 {
-    // The instance record (transforms, offsets, kind). Most scenes have a
-    // handful of instances, so the lanes of a wave usually want the same one:
+    // The instance record (transforms, first triangle, kind). Most scenes have
+    // a handful of instances, so the lanes of a wave usually want the same one:
     // fetch it once through the scalar cache then, per lane otherwise.
     float o2w[12], w2o[12];
-    uint32_t kind, vtx_offset, tri_offset;
+    uint32_t kind, tri_offset;
     const uint32_t first_inst = __builtin_amdgcn_readfirstlane(h.instance);
     if (__builtin_amdgcn_ballot_w64(h.instance != first_inst) == 0ull)
     {
@@ -310,7 +310,6 @@ PTC_DEV Payload closest_hit(const DScene &S, vec3 ray_dir, const Hit &h, uint32_
             w2o[i] = __uint_as_float(w[12 + i]);
         }
         kind = w[24];
-        vtx_offset = w[25];
         tri_offset = w[26];
     }
     else
@@ -323,10 +322,10 @@ PTC_DEV Payload closest_hit(const DScene &S, vec3 ray_dir, const Hit &h, uint32_
             w2o[i] = I->w2o[i];
         }
         kind = I->kind;
-        vtx_offset = I->vtx_offset;
         tri_offset = I->tri_offset;
     }
-    (void)vtx_offset;
+    // the triangle's shading record: positions and normals of its three corners
+    // (what the reference gathers through the index buffer, closest_hit_common.glsl:61-69)
     const float4 *__restrict__ rec = S.shade + 5u * (size_t)(tri_offset + h.primitive);
     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
     const vec3 v0 = v3(r0.x, r0.y, r0.z);
