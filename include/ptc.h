@@ -318,6 +318,16 @@ int ptc_render(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
 int ptc_render_static(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
                       const ptc_camera *camera, const ptc_render_params *params);
 
+/* What ptc_render() (static_workspace = 0) or ptc_render_static() (1) would do
+ * with a call of these parameters on a width x height film, without doing it
+ * and without a device: the bytes of workspace it takes (0 for the megakernel)
+ * and the dispatches it holds in flight per batch. PTC_E_LIMIT, with the
+ * reason in ptc_last_error(), for a call that would be refused. No counterpart
+ * in the reference, whose allocations are the Vulkan driver's. Either output
+ * pointer may be NULL. */
+int ptc_render_workspace(uint32_t width, uint32_t height, const ptc_render_params *params,
+                         int static_workspace, uint64_t *bytes_out, uint32_t *dispatches_per_batch_out);
+
 /* draw_frame() as the reference issues it: the call records its commands and
  * returns while earlier frames still run (frames_in_flight, src/renderer.hpp:208;
  * the queue submit of src/renderer.cpp:2170-2172 does not wait). Same arguments

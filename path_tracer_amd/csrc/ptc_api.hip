@@ -264,6 +264,20 @@ int stage(ptc_context *ctx, size_t bytes, void **out)
     return PTC_OK;
 }
 
+// PTC_INTEGRATOR_AUTO by the call's shape: wavefront for one sample per dispatch
+// or 16+ dispatches in flight per pass, stream otherwise.
+uint32_t resolve_integrator(const DFrame &F, uint32_t integrator)
+{
+    if (integrator != PTC_INTEGRATOR_AUTO)
+    {
+        return integrator;
+    }
+    // dispatches the wavefront integrator would hold in flight per pass
+    const uint64_t per_dispatch = std::max<uint64_t>((uint64_t)F.width * F.height * F.samples_per_frame, 1u);
+    const uint64_t in_flight = std::min<uint64_t>(F.n_frames, std::max<uint64_t>(F.max_paths_in_flight / per_dispatch, 1u));
+    return F.samples_per_frame == 1u || in_flight >= 16u ? PTC_INTEGRATOR_WAVEFRONT : PTC_INTEGRATOR_STREAM;
+}
+
 uint32_t pending_samples(const ptc_film *film)
 {
     return film->pending.params.n_frames * film->pending.params.samples_per_frame;
@@ -973,14 +987,7 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
         PTC_HIP_CHECK(hipEventRecord(ev0, ctx->stream));
     }
     int rc;
-    uint32_t integrator = params->integrator;
-    if (integrator == PTC_INTEGRATOR_AUTO)
-    {
-        // dispatches the wavefront integrator would hold in flight per pass
-        const uint64_t per_dispatch = std::max<uint64_t>((uint64_t)F.width * F.height * F.samples_per_frame, 1u);
-        const uint64_t in_flight = std::min<uint64_t>(F.n_frames, std::max<uint64_t>(F.max_paths_in_flight / per_dispatch, 1u));
-        integrator = F.samples_per_frame == 1u || in_flight >= 16u ? PTC_INTEGRATOR_WAVEFRONT : PTC_INTEGRATOR_STREAM;
-    }
+    const uint32_t integrator = resolve_integrator(F, params->integrator);
     ctx->no_events = static_scratch;
     if (integrator != PTC_INTEGRATOR_MEGAKERNEL)
     {
@@ -1021,6 +1028,49 @@ int ptc_render_static(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, 
                       const ptc_render_params *params)
 {
     return render_impl(ctx, scene, film, camera, params, true);
+}
+
+int ptc_render_workspace(uint32_t width, uint32_t height, const ptc_render_params *params, int static_workspace,
+                         uint64_t *bytes_out, uint32_t *dispatches_per_batch_out)
+{
+    if (!params || width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28))
+    {
+        set_error("ptc_render_workspace: NULL parameters or a film of 0 or more than 2^28 pixels");
+        return PTC_E_INVALID;
+    }
+    if (params->samples_per_frame == 0 || params->n_frames == 0 || params->integrator > PTC_INTEGRATOR_AUTO)
+    {
+        set_error("ptc_render_workspace: samples_per_frame and n_frames must be >= 1, the integrator a known one");
+        return PTC_E_INVALID;
+    }
+    DFrame F{};
+    F.width = width;
+    F.height = height;
+    F.samples_per_frame = params->samples_per_frame;
+    F.n_frames = params->n_frames;
+    F.max_depth = params->max_depth ? params->max_depth : 32u;
+    F.wavefront_bounces = params->wavefront_bounces;
+    F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : (1u << 28);
+    const uint32_t integrator = resolve_integrator(F, params->integrator);
+    WavefrontPlan plan;
+    if (integrator == PTC_INTEGRATOR_MEGAKERNEL)
+    {
+        plan.dispatches_per_batch = params->n_frames; // all dispatches of a pixel run in one lane; no workspace
+    }
+    else if (const int rc = plan_wavefront(F, integrator == PTC_INTEGRATOR_STREAM, static_workspace != 0, &plan);
+             rc != PTC_OK)
+    {
+        return rc;
+    }
+    if (bytes_out)
+    {
+        *bytes_out = plan.bytes;
+    }
+    if (dispatches_per_batch_out)
+    {
+        *dispatches_per_batch_out = plan.dispatches_per_batch;
+    }
+    return PTC_OK;
 }
 
 int ptc_render_deferred(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const ptc_camera *camera,

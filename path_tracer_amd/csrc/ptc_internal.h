@@ -187,6 +187,17 @@ int launch_render_mega(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
 // count: the fused first-bounce kernel also counts nodes / triangles visited.
 int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
                             const DFrame &frame, bool stream, bool static_scratch, bool count);
+// How launch_render_wavefront would run a call (host arithmetic only): the
+// dispatches it holds in flight per batch and the workspace they take; with
+// static_scratch, as bounded by the static array. PTC_E_LIMIT (with the error
+// text set) for a call that cannot run.
+struct WavefrontPlan
+{
+    uint32_t dispatches_per_batch = 0;
+    size_t bytes = 0;
+    bool pairs = false; // bounces run as traversal / shading launch pairs
+};
+int plan_wavefront(const DFrame &frame, bool stream, bool static_scratch, WavefrontPlan *plan);
 // Looks up the device address of the static array on ctx's (current) device.
 int wavefront_static_init(ptc_context *ctx);
 int launch_primary_hits(ptc_context *ctx, const ptc_scene *scene, const DFrame &frame,

@@ -1080,6 +1080,79 @@ size_t workspace_bytes(uint32_t width, uint32_t height, uint32_t spf, uint32_t m
 
 } // namespace
 
+int plan_wavefront(const DFrame &F0, bool stream, bool static_scratch, WavefrontPlan *plan)
+{
+    const uint32_t n_pixels = F0.width * F0.height;
+    const uint32_t spf = F0.samples_per_frame;
+    const bool pairs = F0.wavefront_bounces > 0u && F0.max_depth > 1u; // some bounce runs as a traversal / shading launch pair
+    // dispatches per batch: bounded so the workspace stays bounded (by default 2^28 paths, about 20 GB)
+    uint32_t max_batch = std::max<uint32_t>(
+        1u, std::min<uint64_t>(F0.n_frames,
+                               F0.max_paths_in_flight / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
+    // Path ids and work-item numbers are 32-bit: a batch, with the film padded
+    // to whole 8x8 tiles (the stream integrator's items), must stay below 2^32.
+    {
+        const uint64_t padded = (uint64_t)((F0.width + 7u) >> 3) * ((F0.height + 7u) >> 3) * 64u;
+        const uint64_t fit = 0xffffffffull / (padded * spf);
+        if (fit == 0u)
+        {
+            set_error("ptc_render: width * height * samples_per_frame exceeds 2^32 paths per dispatch");
+            return PTC_E_LIMIT;
+        }
+        max_batch = (uint32_t)std::min<uint64_t>(max_batch, fit);
+    }
+    // A call that takes several batches runs them in whole groups of 64 (or 16)
+    // dispatches: the primary pass deals the dispatches of a pixel to the 64, 32
+    // or 16 lanes of a group, so a batch of 129 would leave 15 of 144 lanes idle
+    // and size the queue for them.
+    auto whole_groups = [&](uint32_t batch) {
+        return batch >= F0.n_frames || batch < 16u ? batch : (batch >= 64u ? batch & ~63u : batch & ~15u);
+    };
+    max_batch = whole_groups(max_batch);
+    // The queue's segments are sized by the blocks of the primary pass, which cover
+    // the film rounded up to whole 32x32-pixel groups: for a film much smaller
+    // than its groups the batch shrinks so that the queue has at most twice the
+    // slots max_paths_in_flight asks for (and fewer than 2^32: slots are 32-bit).
+    if (!stream && !pairs)
+    {
+        const uint64_t bound = std::min<uint64_t>(
+            0xffffffffull, 2u * std::max<uint64_t>(F0.max_paths_in_flight, (uint64_t)n_pixels * spf));
+        while (max_batch > 1u && queue_slots(F0.width, F0.height, max_batch, stream, pairs) > bound)
+        {
+            max_batch = whole_groups(max_batch / 2u);
+        }
+        if (queue_slots(F0.width, F0.height, max_batch, stream, pairs) > 0xffffffffull)
+        {
+            set_error("ptc_render: the film rounded up to 32x32-pixel groups exceeds 2^32 paths per dispatch");
+            return PTC_E_LIMIT;
+        }
+    }
+    auto bytes_for = [&](uint32_t batch) {
+        return workspace_bytes(F0.width, F0.height, spf, batch, F0.max_depth, stream, pairs);
+    };
+    if (static_scratch)
+    {
+        // as many dispatches per batch as the static array holds; one at least
+        while (max_batch > 1u && bytes_for(max_batch) > kStaticScratchBytes)
+        {
+            max_batch = whole_groups(max_batch / 2u);
+        }
+        const size_t need = bytes_for(max_batch);
+        if (need > kStaticScratchBytes)
+        {
+            set_error("ptc_render_static: one dispatch of " + std::to_string(n_pixels) + " pixels x " +
+                      std::to_string(spf) + " samples needs " + std::to_string(need) +
+                      " bytes of workspace, the static array holds " + std::to_string(kStaticScratchBytes) +
+                      " (use ptc_render, a smaller film or fewer samples per frame)");
+            return PTC_E_LIMIT;
+        }
+    }
+    plan->dispatches_per_batch = max_batch;
+    plan->bytes = bytes_for(max_batch);
+    plan->pairs = pairs;
+    return PTC_OK;
+}
+
 int wavefront_static_init(ptc_context *ctx)
 {
     // `scratch` is a host-side stand-in for the device array, not an address a
@@ -1110,66 +1183,21 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     const uint32_t spf = F0.samples_per_frame;
     const bool two_level = scene->d.inst_box != nullptr;
     const uint32_t wf_bounces = F0.wavefront_bounces;
-    const bool pairs = wf_bounces > 0u && F0.max_depth > 1u; // some bounce runs as a traversal / shading launch pair
-    // dispatches per batch: bounded so the workspace stays bounded (by default 2^28 paths, about 20 GB)
-    uint32_t max_batch = std::max<uint32_t>(
-        1u, std::min<uint64_t>(F0.n_frames,
-                               F0.max_paths_in_flight / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));
-    // Path ids and work-item numbers are 32-bit: a batch, with the film padded
-    // to whole 8x8 tiles (the stream integrator's items), must stay below 2^32.
+    WavefrontPlan plan;
+    if (const int rc = plan_wavefront(F0, stream, static_scratch, &plan); rc != PTC_OK)
     {
-        const uint64_t padded = (uint64_t)((F0.width + 7u) >> 3) * ((F0.height + 7u) >> 3) * 64u;
-        const uint64_t fit = 0xffffffffull / (padded * spf);
-        if (fit == 0u)
-        {
-            set_error("ptc_render: width * height * samples_per_frame exceeds 2^32 paths per dispatch");
-            return PTC_E_LIMIT;
-        }
-        max_batch = (uint32_t)std::min<uint64_t>(max_batch, fit);
+        return rc;
     }
-    // The queue's segments are sized by the blocks of the primary pass, which cover
-    // the film rounded up to whole 32x32-pixel groups: for a film much smaller
-    // than its groups the batch shrinks so that the queue has at most twice the
-    // slots max_paths_in_flight asks for (and fewer than 2^32: slots are 32-bit).
-    if (!stream && !pairs)
-    {
-        const uint64_t bound = std::min<uint64_t>(
-            0xffffffffull, 2u * std::max<uint64_t>(F0.max_paths_in_flight, (uint64_t)n_pixels * spf));
-        while (max_batch > 1u && queue_slots(F0.width, F0.height, max_batch, stream, pairs) > bound)
-        {
-            max_batch = max_batch / 2u;
-        }
-        if (queue_slots(F0.width, F0.height, max_batch, stream, pairs) > 0xffffffffull)
-        {
-            set_error("ptc_render: the film rounded up to 32x32-pixel groups exceeds 2^32 paths per dispatch");
-            return PTC_E_LIMIT;
-        }
-    }
+    const bool pairs = plan.pairs;
+    const uint32_t max_batch = plan.dispatches_per_batch;
     const size_t n_counts = counter_words(F0.max_depth);
-    auto bytes_for = [&](uint32_t batch) {
-        return workspace_bytes(F0.width, F0.height, spf, batch, F0.max_depth, stream, pairs);
-    };
     char *workspace = nullptr;
     if (static_scratch)
     {
-        // as many dispatches per batch as the static array holds; one at least
-        if (ctx->static_scratch == nullptr)
+        if (ctx->static_scratch == nullptr || ctx->static_scratch_bytes < plan.bytes)
         {
             set_error("ptc_render_static: the static workspace was not set up on this device");
             return PTC_E_DEVICE;
-        }
-        while (max_batch > 1u && bytes_for(max_batch) > ctx->static_scratch_bytes)
-        {
-            max_batch = max_batch / 2u;
-        }
-        const size_t need = bytes_for(max_batch);
-        if (need > ctx->static_scratch_bytes)
-        {
-            set_error("ptc_render_static: one dispatch of " + std::to_string(n_pixels) + " pixels x " +
-                      std::to_string(spf) + " samples needs " + std::to_string(need) +
-                      " bytes of workspace, the static array holds " + std::to_string(ctx->static_scratch_bytes) +
-                      " (use ptc_render, a smaller film or fewer samples per frame)");
-            return PTC_E_LIMIT;
         }
         workspace = static_cast<char *>(ctx->static_scratch);
     }
@@ -1177,7 +1205,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     // stream mode keeps live paths in registers: only the radiance array is needed
     const size_t qcap = queue_slots(F0.width, F0.height, max_batch, stream, pairs);
     const size_t pcap = pairs && !stream ? cap : 1;
-    const size_t bytes = bytes_for(max_batch);
+    const size_t bytes = plan.bytes;
     if (!static_scratch)
     {
         if (bytes > ctx->wf_bytes)

@@ -110,6 +110,20 @@ class RenderParams(C.Structure):
                 ("tonemap", C.c_uint32), ("max_paths_in_flight", C.c_uint32)]
 
 
+def render_workspace(width: int, height: int, n_frames: int = 1, samples_per_frame: int = 1,
+                     integrator: int = 3, max_depth: int = 32, wavefront_bounces: int = 0,
+                     max_paths_in_flight: int = 0, static: bool = False):
+    """ptc_render_workspace: (bytes of workspace, dispatches in flight per batch)
+    of such a ptc_render / ptc_render_static call; host arithmetic, no device.
+    (integrator 3 = PTC_INTEGRATOR_AUTO.)"""
+    p = RenderParams()
+    p.n_frames, p.samples_per_frame, p.integrator, p.max_depth = n_frames, samples_per_frame, integrator, max_depth
+    p.wavefront_bounces, p.max_paths_in_flight = wavefront_bounces, max_paths_in_flight
+    nbytes, batch = C.c_uint64(0), C.c_uint32(0)
+    _check(lib().ptc_render_workspace(width, height, C.byref(p), int(static), C.byref(nbytes), C.byref(batch)))
+    return nbytes.value, batch.value
+
+
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("render_ms", C.c_double),
@@ -124,7 +138,7 @@ EXPORTS = [
     "ptc_scene_create", "ptc_scene_destroy", "ptc_scene_get_info", "ptc_scene_read_bvh",
     "ptc_film_create", "ptc_film_destroy", "ptc_film_reset", "ptc_film_sample_count",
     "ptc_film_set_sample_count", "ptc_film_read_accum", "ptc_film_read_rgba8",
-    "ptc_film_accum_device_ptr", "ptc_film_resolve", "ptc_render", "ptc_render_static", "ptc_render_deferred", "ptc_film_flush",
+    "ptc_film_accum_device_ptr", "ptc_film_resolve", "ptc_render", "ptc_render_static", "ptc_render_deferred", "ptc_film_flush", "ptc_render_workspace",
     "ptc_primary_hits", "ptc_scene_triangle_ids",
     "ptc_trace_rays", "ptc_trace_rays_device", "ptc_get_stats", "ptc_render_times",
     "ptc_phase_times",
@@ -169,6 +183,8 @@ def lib():
         L.ptc_render.argtypes = [vp, vp, vp, C.POINTER(Camera), C.POINTER(RenderParams)]
         L.ptc_render_static.argtypes = [vp, vp, vp, C.POINTER(Camera), C.POINTER(RenderParams)]
         L.ptc_render_deferred.argtypes = [vp, vp, vp, C.POINTER(Camera), C.POINTER(RenderParams)]
+        L.ptc_render_workspace.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RenderParams), C.c_int,
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.ptc_film_flush.argtypes = [vp]
         L.ptc_primary_hits.argtypes = [vp, vp, C.POINTER(Camera), u32, u32, u32, f32, vp]
         L.ptc_scene_triangle_ids.argtypes = [vp, vp, sz, vp, vp]

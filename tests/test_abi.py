@@ -53,3 +53,43 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pt_oracle" not in text and "oracle/" not in text, f"{f} references the oracle"
+
+
+def test_render_workspace_matches_the_documented_sizes():
+    """ptc_render_workspace is host arithmetic: the figures include/ptc.h and the
+    design notes quote can be checked without a GPU."""
+    # 1080p, the default bound of 2^28 paths: 128 dispatches (129 fit; batches are whole groups of 64) of 2,073,600 pixels in flight, about 76 bytes per path
+    nbytes, batch = R.render_workspace(1920, 1080, n_frames=4096, integrator=R.INTEGRATOR_WAVEFRONT)
+    assert batch == 128
+    per_path = nbytes / (batch * 1920 * 1080)
+    assert 76.0 <= per_path <= 78.5, per_path
+    # launch pairs take the second queue and the hit records
+    nbytes2, batch2 = R.render_workspace(1920, 1080, n_frames=4096, integrator=R.INTEGRATOR_WAVEFRONT,
+                                         wavefront_bounces=2)
+    assert batch2 == 128 and 155.0 <= nbytes2 / (batch2 * 1920 * 1080) <= 157.0
+    # the stream integrator keeps live paths in registers: the radiance array only
+    nbytes3, _ = R.render_workspace(1920, 1080, n_frames=64, samples_per_frame=2, integrator=R.INTEGRATOR_STREAM)
+    assert 32.0 <= nbytes3 / (64 * 1920 * 1080) <= 32.1
+    # the megakernel takes none
+    assert R.render_workspace(1920, 1080, n_frames=7, integrator=R.INTEGRATOR_MEGAKERNEL) == (0, 7)
+    # static workspace (64 MiB): the reference's default film fits twice, 1024x768 once, 1080p not at all
+    assert R.render_workspace(640, 480, n_frames=3, integrator=R.INTEGRATOR_WAVEFRONT, static=True)[1] in (1, 2)
+    nbytes4, batch4 = R.render_workspace(640, 480, n_frames=2, integrator=R.INTEGRATOR_WAVEFRONT, static=True)
+    assert batch4 == 2 and nbytes4 <= 64 << 20
+    assert R.render_workspace(1024, 768, integrator=R.INTEGRATOR_WAVEFRONT, static=True)[1] == 1
+    import pytest
+    with pytest.raises(R.PtcError, match="static array holds 67108864"):
+        R.render_workspace(1920, 1080, integrator=R.INTEGRATOR_WAVEFRONT, static=True)
+    assert R.render_workspace(1920, 1080, integrator=R.INTEGRATOR_STREAM, static=True)[0] <= 64 << 20
+    # a film much smaller than the 32x32-pixel groups the queue covers: smaller batches, never more than twice
+    # the slots the bound asks for
+    nbytes5, batch5 = R.render_workspace(3, 2, n_frames=100000, integrator=R.INTEGRATOR_WAVEFRONT,
+                                         max_paths_in_flight=6 * 1000)
+    assert 1 <= batch5 < 1000 and nbytes5 <= 2 * 6000 * 64 + 6000 * 16 + 65536
+    # AUTO: one sample per dispatch or 16+ dispatches in flight -> wavefront sizes, otherwise stream sizes
+    assert R.render_workspace(640, 480, n_frames=4, samples_per_frame=3) == \
+        R.render_workspace(640, 480, n_frames=4, samples_per_frame=3, integrator=R.INTEGRATOR_STREAM)
+    assert R.render_workspace(640, 480, n_frames=4) == \
+        R.render_workspace(640, 480, n_frames=4, integrator=R.INTEGRATOR_WAVEFRONT)
+    with pytest.raises(R.PtcError):
+        R.render_workspace(0, 480)
