@@ -1138,7 +1138,9 @@ int ptc_render_deferred(ptc_context *ctx, const ptc_scene *scene, ptc_film *film
     // (max_paths_in_flight); more would only wait for the next batch
     const uint64_t per_dispatch = (uint64_t)film->width * film->height * want.samples_per_frame;
     const uint64_t budget = want.max_paths_in_flight ? want.max_paths_in_flight : (1u << 28);
-    const uint64_t bound = std::max<uint64_t>(budget / std::max<uint64_t>(per_dispatch, 1u), 1u);
+    uint64_t bound = std::max<uint64_t>(budget / std::max<uint64_t>(per_dispatch, 1u), 1u);
+    // (whole groups of 64 or 16 dispatches, which the primary pass deals to the lanes of a wave)
+    bound = bound >= 64u ? bound & ~63ull : (bound >= 16u ? bound & ~15ull : bound);
     if (pend.params.n_frames >= bound)
     {
         return flush_film(film);
