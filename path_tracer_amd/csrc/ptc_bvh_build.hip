@@ -260,6 +260,28 @@ __device__ __forceinline__ float merged_half_area(float4 alo, float4 ahi, float4
     return dx * dy + dy * dz + dz * dx;
 }
 
+// Order of a cluster's candidate partners: smaller merged area first; among equal areas the nearer index, and of
+// the two at one distance d the one whose pair starts at an even multiple of d. The last two keys depend on the
+// pair alone, not on which end looks, so clusters with equal boxes (coincident triangles, lattices) still find
+// mutual partners in pairs, (0,1), (2,3) ..., instead of all pointing the same way and merging one pair a round.
+struct Partner
+{
+    float area;
+    int j;
+    uint32_t rank; // (distance << 1) | odd-multiple bit
+};
+__device__ __forceinline__ void consider_partner(Partner &best, int i, int j, float area)
+{
+    const uint32_t d = (uint32_t)(i < j ? j - i : i - j), lower = (uint32_t)(i < j ? i : j);
+    const uint32_t rank = (d << 1) | ((lower / d) & 1u);
+    if (area < best.area || (area == best.area && rank < best.rank))
+    {
+        best.area = area;
+        best.j = j;
+        best.rank = rank;
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_nearest(uint32_t n, int radius, const float4 *__restrict__ cl_lo,
           const float4 *__restrict__ cl_hi, int *__restrict__ nn)
@@ -284,8 +306,7 @@ k_nearest(uint32_t n, int radius, const float4 *__restrict__ cl_lo,
     }
     const int me = threadIdx.x + radius;
     const float4 mlo = s_lo[me], mhi = s_hi[me];
-    float best = INFINITY;
-    int best_j = -1;
+    Partner best = {INFINITY, -1, 0u};
     for (int off = -radius; off <= radius; ++off)
     {
         const long long j = (long long)i + off;
@@ -293,14 +314,9 @@ k_nearest(uint32_t n, int radius, const float4 *__restrict__ cl_lo,
         {
             continue;
         }
-        const float a = merged_half_area(mlo, mhi, s_lo[me + off], s_hi[me + off]);
-        if (a < best)
-        {
-            best = a;
-            best_j = (int)j;
-        }
+        consider_partner(best, (int)i, (int)j, merged_half_area(mlo, mhi, s_lo[me + off], s_hi[me + off]));
     }
-    nn[i] = best_j;
+    nn[i] = best.j;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -407,8 +423,7 @@ k_ploc_tail(uint32_t n, uint32_t n_leaves, uint32_t next_node, int radius,
         if (i < n)
         {
             const float4 mlo = s_lo[cur][i], mhi = s_hi[cur][i];
-            float best = INFINITY;
-            int best_j = -1;
+            Partner best = {INFINITY, -1, 0u};
             for (int off = -radius; off <= radius; ++off)
             {
                 const int j = (int)i + off;
@@ -416,14 +431,9 @@ k_ploc_tail(uint32_t n, uint32_t n_leaves, uint32_t next_node, int radius,
                 {
                     continue;
                 }
-                const float a = merged_half_area(mlo, mhi, s_lo[cur][j], s_hi[cur][j]);
-                if (a < best)
-                {
-                    best = a;
-                    best_j = j;
-                }
+                consider_partner(best, (int)i, j, merged_half_area(mlo, mhi, s_lo[cur][j], s_hi[cur][j]));
             }
-            s_nn[i] = best_j;
+            s_nn[i] = best.j;
         }
         __syncthreads();
         bool merge = false, valid = false;
