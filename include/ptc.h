@@ -103,8 +103,9 @@ typedef struct ptc_envmap_desc
 typedef struct ptc_build_options
 {
     /* Neighbourhood (in Morton order) each cluster searches for its merge
-     * partner during the bottom-up build; 0 selects the default of 16,
-     * values above 32 are clamped. Larger = better tree, slower build. */
+     * partner during the bottom-up build; 0 selects the default of 8,
+     * values above 32 are clamped. Larger = slower build and a slightly lower
+     * surface-area cost, which traversal times follow only loosely. */
     uint32_t search_radius;
     /* 0: every instance's triangles are transformed to world space and go
      * into one tree (fastest traversal; memory grows with the instance count).
