@@ -485,9 +485,12 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // rarer phases (pulling new paths, shading, triangle tests) run when
     // enough lanes of the wave want them, or when a lane has nothing else left.
     constexpr uint32_t kIdle = 0u, kTrav = 1u, kShade = 2u;
-    // lanes that must want a phase before it runs (swept again with the traversal state parked in LDS: 12 to 24
-    // lanes for each of the three are within 1 % of one another, 8 and 32 cost 3 to 7 %)
-    constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 16u, kTriMoreMin = 16u;
+    // lanes that must want a phase before it runs (swept with the traversal state parked in LDS: 12 to 24 lanes
+    // for each of the three are within 1 % of one another on the 871k-triangle scene, 8 and 32 cost 3 to 7 %;
+    // scenes whose paths are shaded more often per node visited want the shading quorum higher: 16 / 20 / 24 /
+    // 32 lanes give 36.1 / 36.0 / 36.4 / 37.4 ms there, 103.2 / 101.6 / 101.4 / 105.8 with the mesh inside
+    // the Cornell box, 27.3 / 25.3 / 24.8 / 24.2 on the Cornell box alone)
+    constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 20u, kTriMoreMin = 16u;
     uint32_t mode = kIdle;
     constexpr uint32_t kChunk = 256u; // work items a wave reserves per atomic (64: Cornell box 17 % slower; 128, 512: within 0.5 %)
     uint32_t chunk_next = 0u, chunk_end = 0u; // this wave's reserved items not handed out yet
