@@ -231,6 +231,17 @@ typedef struct ptc_render_params
      * (about 20 GB: 128 dispatches of a 1920x1080 film); at least one dispatch is
      * always in flight. Does not change results. */
     uint32_t max_paths_in_flight;
+    /* 1: the debug view the reference keeps under "#else" at shader.rgen:195-199:
+     * every sample adds bounces / 16 (the path loop's counter when the path
+     * ended, shader.rgen:65: the iteration it ended in, or max_depth) to its
+     * pixel instead of its radiance. 0: radiance. */
+    uint32_t debug_view;
+    /* Wavefront integrator: 1 hands the paths that survive the first bounce to
+     * the persistent launch sorted by the cell of their ray's origin (Morton
+     * order in the scene's box) and its direction octant, instead of in the
+     * order the first bounce appended them (pixel order). Does not change
+     * results. 0 (default): queue order. */
+    uint32_t regroup;
 } ptc_render_params;
 #define PTC_TONEMAP_PBR_NEUTRAL 0u
 #define PTC_TONEMAP_ACES 1u
@@ -281,13 +292,17 @@ int ptc_scene_read_bvh(const ptc_scene *scene, ptc_bvh8_node *nodes,
 int ptc_film_create(ptc_context *ctx, uint32_t width, uint32_t height,
                     void *accum_dev, void *rgba8_dev, ptc_film **out);
 void ptc_film_destroy(ptc_film *film);
-/* reset_render() (src/renderer.cpp:2236-2239): sample_count = 0. */
+/* reset_render() (src/renderer.cpp:2236-2239): sample_count = 0. The film's
+ * contents stay until the next dispatch overwrites them; dispatches recorded by
+ * ptc_render_deferred() still show in a read-back that comes before it. */
 int ptc_film_reset(ptc_film *film);
 uint32_t ptc_film_sample_count(const ptc_film *film);
 /* Continue from an externally supplied sample count (sharded rendering). */
 int ptc_film_set_sample_count(ptc_film *film, uint32_t sample_count);
 int ptc_film_read_accum(ptc_film *film, float *rgba_out);    /* 4*w*h floats */
 int ptc_film_read_rgba8(ptc_film *film, uint8_t *rgba_out);  /* 4*w*h bytes */
+/* Device address of the RGBA32F accumulator. Launches the film's recorded
+ * dispatches first (asynchronously, on the context's stream). */
 void *ptc_film_accum_device_ptr(ptc_film *film);
 /* Tone-map the accumulator into the RGBA8 target again (after an external
  * reduction wrote the accumulator). sum_mode: divide rgb by alpha first. */
@@ -343,13 +358,21 @@ int ptc_render_workspace(uint32_t width, uint32_t height, const ptc_render_param
  * reads or writes the film (read-backs, ptc_write_png, ptc_film_resolve,
  * ptc_render* -- ptc_render_static launches it through its own static
  * workspace, so it still allocates nothing --, ptc_film_set_sample_count to
- * another count); ptc_film_reset()
- * and ptc_film_destroy() drop it. ptc_film_sample_count() includes the
- * recorded samples. Not covered: a device pointer taken with
- * ptc_film_accum_device_ptr() or handed to ptc_film_create() is only current
- * after ptc_film_flush(). An error of a deferred launch is returned by the call
- * that launches it. The camera and the parameters are copied; the scene must
- * stay alive (ptc_scene_destroy() launches what uses it). */
+ * another count, ptc_film_accum_device_ptr); ptc_film_destroy() drops it.
+ * ptc_film_reset() keeps it: in the reference every earlier draw_frame has been
+ * submitted when reset_render zeroes the counter (src/renderer.cpp:2236-2239),
+ * so whatever reads the film before the next dispatch launches the run first
+ * and sees every submitted frame; the next dispatch, which overwrites the film,
+ * drops it unlaunched. ptc_film_sample_count() includes the recorded samples
+ * (and is 0 after a reset either way). A film over caller-owned memory
+ * (ptc_film_create with accum_dev or rgba8_dev) never records: its dispatches
+ * are launched at once, as by ptc_render(), because such a caller orders its
+ * own work behind them by the stream alone. A launch refused before it started
+ * (PTC_E_LIMIT from ptc_render_static's workspace bound, PTC_E_NOMEM) leaves
+ * the run recorded; any other error of a deferred launch is returned by the
+ * call that launches it and the run is gone. The camera and the parameters are
+ * copied; the scene must stay alive (ptc_scene_destroy() launches what uses
+ * it). */
 int ptc_render_deferred(ptc_context *ctx, const ptc_scene *scene, ptc_film *film,
                         const ptc_camera *camera, const ptc_render_params *params);
 /* Launches the dispatches recorded on the film, if any (asynchronous). */

@@ -1661,12 +1661,17 @@ static void closest_hit(const pt_scene *S, payload_t *P, pt_vec3 ray_dir,
     material_scatter(I->kind, ray_dir, world_position, nrm, P);
 }
 
+/* shader.rgen:60-100; *bounces_out is the loop counter the shader returns
+ * through its out parameter: the iteration the path ended in, max_depth for a
+ * path that ran through all of them */
 static pt_vec3 radiance(const pt_scene *S, payload_t *P,
-                        const pt_render_params *rp, pt_stats *st)
+                        const pt_render_params *rp, pt_stats *st,
+                        uint32_t *bounces_out)
 {
     pt_vec3 accumulated_color = pt_v3(0.0f, 0.0f, 0.0f);
     pt_vec3 accumulated_reflectance = pt_v3(1.0f, 1.0f, 1.0f);
-    for (uint32_t bounces = 0; bounces < rp->max_depth; ++bounces)
+    uint32_t bounces;
+    for (bounces = 0; bounces < rp->max_depth; ++bounces)
     {
         P->attenuation = 1.0f;
         const pt_vec3 ray_dir = P->dir;
@@ -1688,6 +1693,7 @@ static pt_vec3 radiance(const pt_scene *S, payload_t *P,
             pt_add(accumulated_color, pt_mul(accumulated_reflectance, P->emissivity));
         if (P->hit_sky)
         {
+            *bounces_out = bounces;
             return accumulated_color;
         }
         pt_vec3 hit_color = P->color;
@@ -1698,11 +1704,13 @@ static pt_vec3 radiance(const pt_scene *S, payload_t *P,
         }
         else
         {
+            *bounces_out = bounces;
             return accumulated_color;
         }
         accumulated_reflectance = pt_mul(
             accumulated_reflectance, pt_scale(hit_color, P->attenuation));
     }
+    *bounces_out = bounces;
     return accumulated_color;
 }
 
@@ -1720,7 +1728,14 @@ static void raygen(const pt_scene *S, const pt_push_constants *push,
     {
         camera_ray(push, rp->width, rp->height, px, py, &P.rng, &P.origin,
                    &P.dir);
-        const pt_vec3 c = radiance(S, &P, rp, st);
+        uint32_t bounces = 0;
+        pt_vec3 c = radiance(S, &P, rp, st, &bounces);
+        if (rp->debug_view == 1)
+        {
+            /* the branch under "#else" at shader.rgen:197-198 */
+            const float b = (float)bounces / 16.0f;
+            c = pt_v3(b, b, b);
+        }
         st->paths++;
         acc[0] += c.x;
         acc[1] += c.y;

@@ -173,6 +173,7 @@ typedef struct
     int use_bvh;
     int n_threads;       /* 0 = all */
     int tonemap;         /* 0 = PBR neutral (shader.rgen:218-219), 1 = ACES (:220-221) */
+    int debug_view;      /* 1 = each sample adds bounces / 16 instead of its radiance (shader.rgen:195-199) */
 } pt_render_params;
 
 /* n_frames dispatches of shader.rgen main() over the whole image. push holds

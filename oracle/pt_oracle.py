@@ -85,6 +85,7 @@ class RenderParams(C.Structure):
         ("use_bvh", C.c_int),
         ("n_threads", C.c_int),
         ("tonemap", C.c_int),
+        ("debug_view", C.c_int),
     ]
 
 
@@ -340,9 +341,11 @@ class Scene:
 
     def render(self, push: PushConstants, width, height, accum=None, n_frames=1,
                max_depth=32, tmax=10000.0, accumulate_sum=False, use_bvh=True,
-               n_threads=0, want_rgba8=True, tonemap=TONEMAP_PBR_NEUTRAL):
+               n_threads=0, want_rgba8=True, tonemap=TONEMAP_PBR_NEUTRAL, debug_view=0):
+        """debug_view=1: every sample adds its bounce count / 16 instead of its
+        radiance (the branch under "#else" at shader.rgen:197-198)."""
         rp = RenderParams(width, height, max_depth, tmax, n_frames,
-                          int(accumulate_sum), int(use_bvh), n_threads, int(tonemap))
+                          int(accumulate_sum), int(use_bvh), n_threads, int(tonemap), int(debug_view))
         if accum is None:
             accum = np.zeros((height, width, 4), np.float32)
         else:
@@ -354,11 +357,11 @@ class Scene:
         return accum, rgba8, st
 
     def render_pixels(self, push: PushConstants, width, height, pixel_indices, n_frames=1, max_depth=32,
-                      tmax=10000.0, accumulate_sum=False, use_bvh=True, tonemap=TONEMAP_PBR_NEUTRAL):
+                      tmax=10000.0, accumulate_sum=False, use_bvh=True, tonemap=TONEMAP_PBR_NEUTRAL, debug_view=0):
         """The film pt_render() would leave in the chosen pixels (index = py * width + px)
         of a fresh width x height film: (accum f32[n, 4], rgba8 u8[n, 4], stats)."""
         rp = RenderParams(width, height, max_depth, tmax, n_frames, int(accumulate_sum), int(use_bvh), 0,
-                          int(tonemap))
+                          int(tonemap), int(debug_view))
         idx = np.ascontiguousarray(pixel_indices, dtype=np.uint32).ravel()
         accum = np.zeros((idx.size, 4), np.float32)
         rgba8 = np.zeros((idx.size, 4), np.uint8)
@@ -369,7 +372,7 @@ class Scene:
 
     def primary_hits(self, push: PushConstants, width, height, tmax=10000.0,
                      use_bvh=True):
-        rp = RenderParams(width, height, 32, tmax, 1, 0, int(use_bvh), 0, 0)
+        rp = RenderParams(width, height, 32, tmax, 1, 0, int(use_bvh), 0, 0, 0)
         ids = np.empty((height, width), np.uint32)
         lib().pt_primary_hits(self.handle, C.byref(push), C.byref(rp), _ptr(ids))
         return ids

@@ -220,9 +220,39 @@ int flush_film(ptc_film *film, bool static_scratch = false)
         return PTC_OK;
     }
     const ptc_film::Pending job = film->pending;
+    const bool reset_after = film->reset_pending;
     film->pending.params.n_frames = 0u;
     film->pending.scene = nullptr;
-    return render_impl(film->ctx, job.scene, film, &job.camera, &job.params, static_scratch);
+    film->reset_pending = false;
+    const int rc = render_impl(film->ctx, job.scene, film, &job.camera, &job.params, static_scratch);
+    if (rc == PTC_E_LIMIT || rc == PTC_E_NOMEM)
+    {
+        // refused before anything was launched (the run does not fit the static
+        // workspace, or the workspace could not be allocated): the run stays
+        // recorded, so the film's sample count still tells the truth and another
+        // call (ptc_film_flush after a ptc_render_static, say) can launch it
+        film->pending = job;
+        film->reset_pending = reset_after;
+        return rc;
+    }
+    if (reset_after)
+    {
+        film->sample_count = 0; // the reset that came after the run was recorded
+    }
+    return rc;
+}
+
+// A dispatch is about to overwrite a film that was reset with a run recorded:
+// the run need not be launched any more.
+void drop_reset_run(ptc_film *film)
+{
+    if (film->reset_pending)
+    {
+        film->pending.params.n_frames = 0u;
+        film->pending.scene = nullptr;
+        film->reset_pending = false;
+        film->sample_count = 0;
+    }
 }
 
 // Every film of the context; with a scene given, only the films whose recorded
@@ -281,6 +311,13 @@ uint32_t resolve_integrator(const DFrame &F, uint32_t integrator)
 uint32_t pending_samples(const ptc_film *film)
 {
     return film->pending.params.n_frames * film->pending.params.samples_per_frame;
+}
+
+// The film's sample count as the caller sees it: recorded dispatches included,
+// zero after a reset (whether or not the run recorded before it has been launched).
+uint64_t visible_samples(const ptc_film *film)
+{
+    return film->reset_pending ? 0u : (uint64_t)film->sample_count + pending_samples(film);
 }
 } // namespace
 
@@ -813,16 +850,23 @@ int ptc_film_reset(ptc_film *film)
         set_error("ptc_film_reset: film is NULL");
         return PTC_E_INVALID;
     }
-    // the next dispatch overwrites the film, so dispatches recorded and not yet launched need not run
-    film->pending.params.n_frames = 0u;
-    film->pending.scene = nullptr;
-    film->sample_count = 0;
+    if (film->pending.params.n_frames != 0u)
+    {
+        // Dispatches recorded and not launched yet: in the reference they have been
+        // submitted, so a read-back before the next dispatch shows them. They stay
+        // recorded; what reads the film launches them, the next dispatch drops them.
+        film->reset_pending = true;
+    }
+    else
+    {
+        film->sample_count = 0;
+    }
     return PTC_OK;
 }
 
 uint32_t ptc_film_sample_count(const ptc_film *film)
 {
-    return film ? film->sample_count + pending_samples(film) : 0u;
+    return film ? (uint32_t)visible_samples(film) : 0u;
 }
 
 int ptc_film_set_sample_count(ptc_film *film, uint32_t sample_count)
@@ -832,7 +876,7 @@ int ptc_film_set_sample_count(ptc_film *film, uint32_t sample_count)
         set_error("ptc_film_set_sample_count: film is NULL");
         return PTC_E_INVALID;
     }
-    if (sample_count == film->sample_count + pending_samples(film))
+    if (sample_count == visible_samples(film))
     {
         return PTC_OK; // already there, recorded dispatches included
     }
@@ -885,7 +929,19 @@ int ptc_film_read_rgba8(ptc_film *film, uint8_t *rgba_out)
 
 void *ptc_film_accum_device_ptr(ptc_film *film)
 {
-    return film ? film->d_accum : nullptr;
+    if (!film)
+    {
+        return nullptr;
+    }
+    // like the read-backs: what the pointer shows includes every recorded dispatch
+    // (launched on the context's stream; work the caller enqueues there afterwards
+    // is ordered behind it). An error of that launch is reported by the next call
+    // that flushes.
+    if (use_device(film->ctx) == PTC_OK)
+    {
+        (void)flush_film(film);
+    }
+    return film->d_accum;
 }
 
 int ptc_film_resolve(ptc_film *film, int sum_mode)
@@ -937,7 +993,7 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
         return PTC_E_INVALID;
     }
     const uint64_t added = (uint64_t)params->samples_per_frame * params->n_frames;
-    if ((uint64_t)film->sample_count + pending_samples(film) + added > 0xffffffffull)
+    if (visible_samples(film) + added > 0xffffffffull)
     {
         set_error("ptc_render: sample count overflow");
         return PTC_E_LIMIT;
@@ -946,7 +1002,9 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
     {
         return PTC_E_DEVICE;
     }
-    // dispatches recorded on this film come first (never the case when this is the flush itself)
+    // dispatches recorded on this film come first (never the case when this is the flush itself),
+    // unless the film was reset after them: this call overwrites what they would render
+    drop_reset_run(film);
     if (const int rc = flush_film(film, static_scratch); rc != PTC_OK)
     {
         return rc;
@@ -969,6 +1027,13 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
     film->tonemap = params->tonemap;
     F.wavefront_bounces = params->wavefront_bounces;
     F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : (1u << 28);
+    if (params->debug_view > 1u || params->regroup > 1u)
+    {
+        set_error("ptc_render: unknown debug_view or regroup value");
+        return PTC_E_INVALID;
+    }
+    F.debug_view = params->debug_view;
+    F.regroup = params->regroup;
     // one event pair per call, kept until ptc_render_times() collects them
     // (the static variant records none: creating events allocates)
     constexpr size_t kMaxTimed = 256;
@@ -1092,17 +1157,27 @@ int ptc_render_deferred(ptc_context *ctx, const ptc_scene *scene, ptc_film *film
         return PTC_E_INVALID;
     }
     if (params->integrator > PTC_INTEGRATOR_AUTO || params->accumulate > PTC_ACCUM_SUM ||
-        params->tonemap > PTC_TONEMAP_ACES)
+        params->tonemap > PTC_TONEMAP_ACES || params->debug_view > 1u || params->regroup > 1u)
     {
-        set_error("ptc_render_deferred: unknown integrator, accumulation mode or tonemap");
+        set_error("ptc_render_deferred: unknown integrator, accumulation mode, tonemap, debug_view or regroup value");
         return PTC_E_INVALID;
     }
     const uint64_t added = (uint64_t)params->samples_per_frame * params->n_frames;
-    if ((uint64_t)film->sample_count + pending_samples(film) + added > 0xffffffffull)
+    if (visible_samples(film) + added > 0xffffffffull)
     {
         set_error("ptc_render_deferred: sample count overflow");
         return PTC_E_LIMIT;
     }
+    // A film over memory of the caller's (ptc_film_create with accum_dev or
+    // rgba8_dev) is launched at once: such a caller orders its own work after the
+    // dispatch by the stream (a reduction of the accumulator enqueued behind it, an
+    // event, a stream synchronisation), and a dispatch that is only recorded would
+    // not be on the stream yet.
+    if (!film->own_accum || !film->own_rgba8)
+    {
+        return render_impl(ctx, scene, film, camera, params, false);
+    }
+    drop_reset_run(film); // this dispatch overwrites a film that was reset after its recorded run
     ptc_render_params want = *params;
     want.frame_stride = want.frame_stride ? want.frame_stride : 1u;
     ptc_film::Pending &pend = film->pending;

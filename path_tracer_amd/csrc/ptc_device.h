@@ -79,6 +79,8 @@ struct DFrame
     uint32_t tonemap; // PTC_TONEMAP_*
     uint32_t wavefront_bounces; // bounces run as trace / shade launch pairs before the drain launch
     uint32_t max_paths_in_flight; // workspace bound of the queue-based integrators
+    uint32_t debug_view; // 1: a sample contributes bounces / 16 instead of its radiance (shader.rgen:195-199)
+    uint32_t regroup;    // wavefront integrator: the queue is handed to the persistent launch sorted by ray origin and octant
 };
 
 struct Hit
@@ -1062,6 +1064,16 @@ PTC_DEV Hit trace_scene(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *lds_
 
 // ---- path loop: shader.rgen:60-100 -------------------------------------------
 
+// What a finished sample adds to its pixel: its radiance, or with the debug view
+// of shader.rgen:195-199 (the branch under "#else") the value of the path loop's
+// counter when the path ended, over 16. `bounces` is that counter: the iteration
+// the path ended in, or max_depth for a path that ran through all of them.
+PTC_DEV vec3 sample_value(uint32_t debug_view, vec3 radiance, uint32_t bounces)
+{
+    const float b = (float)bounces / 16.0f;
+    return debug_view == 1u ? v3(b, b, b) : radiance;
+}
+
 template <bool kCount, bool kTwoLevel>
 PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, vec3 origin, vec3 dir, uint32_t &rng_io, uint2 *lds_stack,
                       uint32_t stride, uint32_t &rays, TraceCounters *ctr)
@@ -1072,7 +1084,8 @@ PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, vec3 origin, vec3 dir, u
     ps.throughput = v3(1.0f, 1.0f, 1.0f);
     ps.radiance = v3(0.0f, 0.0f, 0.0f);
     ps.rng = rng_io;
-    for (uint32_t bounces = 0; bounces < f.max_depth; ++bounces)
+    uint32_t bounces;
+    for (bounces = 0; bounces < f.max_depth; ++bounces)
     {
         // counting runs use the reproducible visit order, plain runs the faster one
         const Hit h = trace_scene<kCount, kTwoLevel>(S, ps.origin, ps.dir, f.tmax, lds_stack, stride, ctr);
@@ -1083,7 +1096,7 @@ PTC_DEV vec3 radiance(const DScene &S, const DFrame &f, vec3 origin, vec3 dir, u
         }
     }
     rng_io = ps.rng;
-    return ps.radiance;
+    return sample_value(f.debug_view, ps.radiance, bounces);
 }
 
 // running mean of shader.rgen:202-216 (or the plain sum used when samples are

@@ -109,6 +109,13 @@ struct ptc_film
         ptc_camera camera{};
         ptc_render_params params{};
     } pending;
+    // ptc_film_reset() came while dispatches were recorded. The reference's
+    // reset_render only zeroes the counter (src/renderer.cpp:2236-2239) and every
+    // earlier draw_frame has been submitted, so the recorded run stays launchable:
+    // whatever reads the film before the next dispatch launches it first (the film
+    // then holds every submitted frame), and the next dispatch, which overwrites
+    // the film, drops it. sample_count keeps the run's base count until then.
+    bool reset_pending = false;
 };
 
 namespace ptc

@@ -209,6 +209,7 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
     ps.origin = ps.dir = ps.throughput = ps.radiance = v3(0.0f, 0.0f, 0.0f);
     ps.rng = 0u;
     uint32_t pid = 0;
+    uint32_t ended_in = 0u; // the path loop's counter when this pass ends the path
     if (inside)
     {
         const uint32_t pixel_index = py * F.width + px;
@@ -229,11 +230,13 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
                 h = trace_scene<kCount, kTwoLevel, kPrimaryLds>(S, ps.origin, ps.dir, F.tmax, s_stack + threadIdx.x,
                                                                 kBlock, &ctr);
             }
-            alive = path_bounce(S, h, ps) && F.max_depth > 1u;
+            const bool goes_on = path_bounce(S, h, ps);
+            alive = goes_on && F.max_depth > 1u;
+            ended_in = goes_on ? 1u : 0u;
         }
         if (!alive)
         {
-            finish_path(B, pid, ps.radiance, ps.rng);
+            finish_path(B, pid, sample_value(F.debug_view, ps.radiance, ended_in), ps.rng);
         }
     }
     // One atomic per block (the four waves' counts are combined in LDS): with
@@ -309,7 +312,7 @@ k_wf_trace(DScene S, float tmax, WfState q, float4 *__restrict__ hit, uint2 *__r
 // about 10 ns each, 16 ms for the 1.6 M waves of a 100 M-path bounce.
 constexpr int kShadeBlock = 1024;
 __global__ void __launch_bounds__(kShadeBlock)
-k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
+k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src, uint32_t debug_view)
 {
     __shared__ uint32_t s_alive[kShadeBlock / 64];
     const WfState qi = B.q[src], qo = B.q[src ^ 1];
@@ -333,10 +336,11 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src)
             h.flat = __float_as_uint(hr.w);
             h.instance = hid.x;
             h.primitive = hid.y;
-            alive = path_bounce(S, h, ps) && (bounce + 1u) < max_depth;
+            const bool goes_on = path_bounce(S, h, ps);
+            alive = goes_on && (bounce + 1u) < max_depth;
             if (!alive)
             {
-                finish_path(B, pid, ps.radiance, ps.rng);
+                finish_path(B, pid, sample_value(debug_view, ps.radiance, goes_on ? bounce + 1u : bounce), ps.rng);
             }
         }
         const unsigned long long mask = __ballot(alive);
@@ -613,7 +617,10 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 ps.rng = PTC_WORD(6);
                 uint32_t pid = PTC_WORD(7);
                 uint32_t bounce = PTC_WORD(8);
-                const bool alive = path_bounce(S, best, ps) && (bounce + 1u) < max_depth;
+                const bool goes_on = path_bounce(S, best, ps);
+                const bool alive = goes_on && (bounce + 1u) < max_depth;
+                // the path loop's counter if the path ends here (shader.rgen:65, :193)
+                const uint32_t ended_in = goes_on ? bounce + 1u : bounce;
                 ++bounce;
                 if (alive)
                 {
@@ -621,7 +628,8 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 }
                 else if (kCamera)
                 {
-                    B.radiance[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, 1.0f);
+                    const vec3 value = sample_value(F.debug_view, ps.radiance, ended_in);
+                    B.radiance[pid] = make_float4(value.x, value.y, value.z, 1.0f);
                     const uint32_t sample = PTC_WORD(11) + 1u;
                     if (sample < B.spf)
                     {
@@ -639,7 +647,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 }
                 else
                 {
-                    finish_path(B, pid, ps.radiance, ps.rng);
+                    finish_path(B, pid, sample_value(F.debug_view, ps.radiance, ended_in), ps.rng);
                     mode = kIdle;
                 }
                 org = ps.origin;
@@ -1217,7 +1225,14 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             (void)hipFree(ctx->wf_buf);
             ctx->wf_buf = nullptr;
             ctx->wf_bytes = 0;
-            PTC_HIP_CHECK(hipMalloc(&ctx->wf_buf, bytes));
+            if (hipMalloc(&ctx->wf_buf, bytes) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                ctx->wf_buf = nullptr;
+                set_error("ptc_render: out of device memory for " + std::to_string(bytes) +
+                          " bytes of workspace (lower max_paths_in_flight)");
+                return PTC_E_NOMEM; // nothing was launched
+            }
             ctx->wf_bytes = bytes;
         }
         workspace = static_cast<char *>(ctx->wf_buf);
@@ -1311,7 +1326,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
                 PhaseTimer timer(ctx, PTC_PHASE_BOUNCE);
                 const int src = (int)(b & 1u); // the primary pass writes set 1
                 k_wf_trace<<<blocks, kBlock, 0, st>>>(scene->d, F0.tmax, B.q[src], B.hit, B.hit_ids, B.counts + b);
-                k_wf_shade<<<std::max(1u, blocks / (kShadeBlock / kBlock)), kShadeBlock, 0, st>>>(scene->d, B, b, F0.max_depth, src);
+                k_wf_shade<<<std::max(1u, blocks / (kShadeBlock / kBlock)), kShadeBlock, 0, st>>>(scene->d, B, b, F0.max_depth, src, F0.debug_view);
             }
             // whatever is still alive runs to its end in one persistent launch
             if (drain_b < F0.max_depth)

@@ -126,6 +126,7 @@ struct Render_resources
     std::uint32_t max_depth {32};            // literal of shader.rgen:65
     std::uint32_t integrator {PTC_INTEGRATOR_AUTO};
     std::uint32_t tonemap {PTC_TONEMAP_PBR_NEUTRAL}; // shader.rgen:218-221
+    std::uint32_t debug_view {0};            // 1 = bounce counts / 16, the "#else" branch of shader.rgen:195-199
 
     Render_resources() = default;
     Render_resources(const Render_resources &) = delete;
@@ -143,6 +144,7 @@ struct Render_resources
         std::swap(max_depth, o.max_depth);
         std::swap(integrator, o.integrator);
         std::swap(tonemap, o.tonemap);
+        std::swap(debug_view, o.debug_view);
         return *this;
     }
     ~Render_resources()
@@ -259,9 +261,15 @@ inline void draw_frame(Render_context &context, Render_resources &rr, const Came
         p.max_depth = rr.max_depth;
         p.integrator = rr.integrator;
         p.tonemap = rr.tonemap;
+        p.debug_view = rr.debug_view;
         p.accumulate = PTC_ACCUM_RUNNING_MEAN;
         detail::check(ptc_film_set_sample_count(rr.film, rr.sample_count), "draw_frame");
-        detail::check(ptc_render_deferred(context.handle, rr.scene, rr.film, &camera, &p), "draw_frame");
+        if (const int rc = ptc_render_deferred(context.handle, rr.scene, rr.film, &camera, &p); rc != PTC_OK)
+        {
+            // the call may have launched earlier dispatches and failed in them: the film knows what it holds
+            rr.sample_count = ptc_film_sample_count(rr.film);
+            detail::check(rc, "draw_frame");
+        }
         rr.sample_count += samples_this_frame;
     }
     ++context.global_frame_count;
@@ -291,9 +299,14 @@ inline void draw_frames(Render_context &context, Render_resources &rr, const Cam
         p.max_depth = rr.max_depth;
         p.integrator = rr.integrator;
         p.tonemap = rr.tonemap;
+        p.debug_view = rr.debug_view;
         p.accumulate = PTC_ACCUM_RUNNING_MEAN;
         detail::check(ptc_film_set_sample_count(rr.film, rr.sample_count), "draw_frames");
-        detail::check(ptc_render(context.handle, rr.scene, rr.film, &camera, &p), "draw_frames");
+        if (const int rc = ptc_render(context.handle, rr.scene, rr.film, &camera, &p); rc != PTC_OK)
+        {
+            rr.sample_count = ptc_film_sample_count(rr.film);
+            detail::check(rc, "draw_frames");
+        }
         rr.sample_count += n_full * spf;
         context.global_frame_count += n_full;
         n -= n_full;

@@ -107,7 +107,8 @@ class RenderParams(C.Structure):
                 ("max_depth", C.c_uint32), ("tmax", C.c_float),
                 ("integrator", C.c_uint32), ("accumulate", C.c_uint32),
                 ("instrument", C.c_uint32), ("wavefront_bounces", C.c_uint32),
-                ("tonemap", C.c_uint32), ("max_paths_in_flight", C.c_uint32)]
+                ("tonemap", C.c_uint32), ("max_paths_in_flight", C.c_uint32),
+                ("debug_view", C.c_uint32), ("regroup", C.c_uint32)]
 
 
 def render_workspace(width: int, height: int, n_frames: int = 1, samples_per_frame: int = 1,
@@ -507,6 +508,8 @@ class RenderResources:
         self.wavefront_bounces = 0  # 0 = library default
         self.max_paths_in_flight = 0  # 0 = library default (2^28)
         self.tonemap = TONEMAP_PBR_NEUTRAL  # the one the reference compiles in (shader.rgen:218-219)
+        self.debug_view = 0  # 1 = bounce counts / 16 instead of radiance (shader.rgen:195-199, the "#else" branch)
+        self.regroup = 0  # 1 = the wavefront integrator sorts the queue by ray origin cell and octant
         # draw_frame() records its dispatch and returns, as the reference's does with its frames in flight
         # (src/renderer.hpp:208); False = every draw_frame() launches its own dispatch at once
         self.frames_in_flight = True
@@ -538,6 +541,8 @@ class RenderResources:
         p.wavefront_bounces = self.wavefront_bounces
         p.max_paths_in_flight = self.max_paths_in_flight
         p.tonemap = self.tonemap
+        p.debug_view = self.debug_view
+        p.regroup = self.regroup
         call = lib().ptc_render_static if static else lib().ptc_render_deferred if deferred else lib().ptc_render
         _check(call(self.ctx.handle, self.scene.handle, self.film, C.byref(camera), C.byref(p)))
 

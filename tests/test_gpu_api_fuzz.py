@@ -21,9 +21,9 @@ def _bits(a):
 
 
 def _check(a, b, what):
+    # (also right after a reset: the reference's reset_render only zeroes the counter, src/renderer.cpp:2236-2239,
+    # so until the next dispatch the film shows every frame submitted before it, recorded ones included)
     assert a.sample_count == b.sample_count, what
-    if a.sample_count == 0:
-        return  # reset and not rendered since: the next dispatch overwrites whatever the film holds
     assert np.array_equal(_bits(a.read_accum()), _bits(b.read_accum())), what
     assert np.array_equal(a.read_rgba8(), b.read_rgba8()), what
 

@@ -278,7 +278,7 @@ def test_draw_frame_with_frames_in_flight_equals_immediate_dispatches(ctx):
         ctx.global_frame_count = 7
         R.reset_render(rr)
         for _ in range(3):
-            R.draw_frame(ctx, rr, cam_a)  # dropped by the reset below, as an overwritten film would be
+            R.draw_frame(ctx, rr, cam_a)  # reset below; launched all the same by the statistics reset, which flushes
         R.reset_render(rr)
         assert rr.sample_count == 0
         ctx.reset_stats()
@@ -307,6 +307,114 @@ def test_draw_frame_with_frames_in_flight_equals_immediate_dispatches(ctx):
     rr = R.RenderResources(ctx, w, h, dev)
     R.draw_frame(ctx, rr, cam_a)
     rr.close()
+    dev.close()
+
+
+def test_reset_keeps_a_recorded_run_until_the_next_dispatch(ctx):
+    """reset_render() only zeroes the counter (src/renderer.cpp:2236-2239) and every
+    earlier draw_frame has been submitted: a read-back between the reset and the
+    next dispatch shows all of them, recorded ones included; the next dispatch
+    overwrites the film, so a run still recorded then is dropped unlaunched."""
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(ctx, sc)
+    w, h = 40, 24
+    cam = R.default_camera(w, h)
+    ref = R.RenderResources(ctx, w, h, dev)
+    ref.max_depth = 5
+    ref.render(cam, frame=3, n_frames=3)
+    three = (ref.read_accum(), ref.read_rgba8())
+    R.reset_render(ref)
+    ref.render(cam, frame=6, n_frames=1)
+    one = (ref.read_accum(), ref.read_rgba8())
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.max_depth = 5
+    ctx.global_frame_count = 3
+    for _ in range(3):
+        R.draw_frame(ctx, rr, cam)
+    R.reset_render(rr)
+    assert rr.sample_count == 0
+    assert np.array_equal(_bits(rr.read_accum()), _bits(three[0]))  # the read launches the recorded run
+    assert np.array_equal(rr.read_rgba8(), three[1])
+    assert rr.sample_count == 0
+    R.draw_frame(ctx, rr, cam)  # frame 6 on a reset film
+    assert rr.sample_count == 1
+    assert np.array_equal(_bits(rr.read_accum()), _bits(one[0]))
+    assert np.array_equal(rr.read_rgba8(), one[1])
+    # reset, then a dispatch straight away: the recorded run is never launched
+    ctx.global_frame_count = 3
+    R.reset_render(rr)
+    ctx.reset_stats()
+    for _ in range(3):
+        R.draw_frame(ctx, rr, cam)
+    R.reset_render(rr)
+    R.reset_render(rr)
+    ctx.global_frame_count = 6
+    R.draw_frame(ctx, rr, cam)
+    assert rr.sample_count == 1
+    assert ctx.stats().paths == w * h  # one dispatch ran, not four
+    assert np.array_equal(_bits(rr.read_accum()), _bits(one[0]))
+    # a sample count supplied from outside after the reset continues from what the film then holds
+    ctx.global_frame_count = 3
+    R.reset_render(rr)
+    for _ in range(3):
+        R.draw_frame(ctx, rr, cam)
+    R.reset_render(rr)
+    rr.sample_count = 3  # "the film holds three samples": it does once the run is launched
+    assert np.array_equal(_bits(rr.read_accum()), _bits(three[0]))
+    assert rr.sample_count == 3
+    rr.close()
+    ref.close()
+    dev.close()
+
+
+def test_film_over_caller_memory_is_ordered_by_the_stream_alone(ctx):
+    """A film over caller-owned device memory never records: draw_frame() launches
+    its dispatch at once, so a caller that orders by the stream only (a
+    collective or a copy enqueued behind it, a stream synchronisation) sees every
+    dispatch. The accumulator's device pointer of a library-owned film launches
+    what is recorded."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.cornell_box(short_kind=1)
+    dev = R.DeviceScene(ctx, sc)
+    w, h = 48, 24
+    cam = R.default_camera(w, h)
+    ref = R.RenderResources(ctx, w, h, dev)
+    ref.max_depth = 4
+    ref.render(cam, frame=11, n_frames=5)
+    want = ref.read_accum()
+    own = R.create_context(0)
+    stream = torch.cuda.Stream(device="cuda:0")
+    own.set_stream(stream.cuda_stream)
+    dev2 = R.DeviceScene(own, sc)
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    rr = R.RenderResources(own, w, h, dev2, accum_dev=accum.data_ptr())
+    rr.max_depth = 4
+    own.global_frame_count = 11
+    for _ in range(5):
+        R.draw_frame(own, rr, cam)  # frames_in_flight is on by default
+    with torch.cuda.stream(stream):
+        copy = accum.clone()  # enqueued behind the dispatches on the same stream
+    stream.synchronize()      # no library call in between
+    assert np.array_equal(_bits(copy.cpu().numpy()), _bits(want))
+    rr.close()
+    # library-owned film: the pointer accessor launches the recorded run
+    rr = R.RenderResources(own, w, h, dev2)
+    rr.max_depth = 4
+    own.global_frame_count = 11
+    for _ in range(5):
+        R.draw_frame(own, rr, cam)
+    ptr = rr.accum_device_ptr()
+    stream.synchronize()
+    class DeviceArray:  # the film's accumulator as torch sees foreign device memory
+        __cuda_array_interface__ = dict(shape=(h, w, 4), typestr="<f4", data=(ptr, False), version=2)
+
+    view = torch.as_tensor(DeviceArray(), device="cuda:0")
+    assert np.array_equal(_bits(view.cpu().numpy()), _bits(want))
+    rr.close()
+    dev2.close()
+    own.close()
+    ref.close()
     dev.close()
 
 

@@ -134,6 +134,36 @@ def test_render_bit_exact(scene_pair, ctx, oracle, spf, n_frames, integrator):
     rr.close()
 
 
+@pytest.mark.parametrize("integrator", [R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM],
+                         ids=["megakernel", "wavefront", "stream"])
+@pytest.mark.parametrize("max_depth,wavefront_bounces", [(8, 0), (3, 0), (1, 0), (6, 2)])
+def test_bounce_count_debug_view_bit_exact(scene_pair, ctx, oracle, integrator, max_depth, wavefront_bounces):
+    """The debug view the reference keeps under "#else" (shader.rgen:195-199): each
+    sample adds bounces / 16, the path loop's counter when the path ended. Paths
+    that run through all max_depth iterations, that end at the sky and that end
+    by Russian roulette all occur in these scenes; every integrator ends paths
+    in different kernels (first-bounce pass, launch pairs, persistent launch)."""
+    name, sc, dev, orc = scene_pair
+    w, h = 64, 40
+    cam = R.default_camera(w, h)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.max_depth, rr.integrator, rr.debug_view, rr.wavefront_bounces = max_depth, integrator, 1, wavefront_bounces
+    rr.render(cam, frame=9, samples_per_frame=2, n_frames=2)
+    rr.render(cam, frame=11, samples_per_frame=1, n_frames=17)  # the pixel-major first-bounce pass
+    acc, img = rr.read_accum(), rr.read_rgba8()
+    use_bvh = orc.n_triangles > 2000
+    ref_acc, _, _ = orc.render(oracle.make_push(cam.as_dict(), frame=9, samples_per_frame=2), w, h, n_frames=2,
+                               max_depth=max_depth, use_bvh=use_bvh, debug_view=1)
+    ref_acc, ref_img, _ = orc.render(oracle.make_push(cam.as_dict(), frame=11, sample_count=4), w, h, accum=ref_acc,
+                                     n_frames=17, max_depth=max_depth, use_bvh=use_bvh, debug_view=1)
+    assert np.array_equal(_bits(acc), _bits(ref_acc))
+    assert np.array_equal(img, ref_img)
+    assert acc[..., :3].max() <= max_depth / 16.0
+    if max_depth == 1 and name.startswith("cornell"):
+        assert acc[..., :3].max() > 0.0  # camera paths that survive their only iteration count 1
+    rr.close()
+
+
 @pytest.mark.parametrize("spf,n_frames", [(1, 40), (1, 70), (2, 33)])
 def test_large_batches_bit_exact(ctx, oracle, spf, n_frames):
     """Batches of 32 and more dispatches take the primary pass's other mapping

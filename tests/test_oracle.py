@@ -291,6 +291,33 @@ def test_running_mean_equals_batched_dispatches(oracle):
     assert (acc[..., 3] == 1.0).all()
 
 
+def test_debug_view_counts_the_path_loop(oracle):
+    """shader.rgen:195-199, the branch under "#else": a sample is worth
+    bounces / 16, where bounces is the loop counter of radiance() when it
+    returned (shader.rgen:65): 0 for a camera ray that reaches the sky, the
+    iteration of the miss or of the failed roulette otherwise, max_depth for a
+    path that survives every iteration."""
+    cam = R.default_camera(24, 16)
+    push = oracle.make_push(cam.as_dict(), frame=2)
+    # no triangles: every camera ray reaches the sky in iteration 0
+    empty = oracle.Scene([], [], None)
+    acc, img, st = empty.render(push, 24, 16, n_frames=2, debug_view=1)
+    assert (acc[..., :3] == 0.0).all() and (acc[..., 3] == 1.0).all() and st.rays == 2 * 24 * 16
+    # closed box, one iteration allowed: a sample is 1/16 if the path survived its roulette, else 0
+    sc = scenes.cornell_box()
+    orc = oracle.Scene(*sc.oracle_args())
+    acc, _, _ = orc.render(push, 24, 16, n_frames=1, max_depth=1, use_bvh=False, debug_view=1)
+    assert set(np.unique(acc[..., 0])) <= {0.0, 1.0 / 16.0} and acc[..., 0].max() == 1.0 / 16.0
+    # the mean over dispatches of integers / 16 never exceeds max_depth / 16, and relates to the ray count:
+    # a path that ended in iteration b traced b + 1 rays, one that ran through all of them max_depth
+    acc, _, st = orc.render(push, 24, 16, n_frames=1, max_depth=5, use_bvh=False, debug_view=1)
+    b = np.rint(acc[..., 0] * 16.0).astype(int)
+    assert np.array_equal(acc[..., 0], b / np.float32(16.0)) and b.max() <= 5
+    assert b.sum() <= st.rays <= b.sum() + 24 * 16
+    plain, _, st_plain = orc.render(push, 24, 16, n_frames=1, max_depth=5, use_bvh=False)
+    assert st_plain.rays == st.rays  # the view changes what is accumulated, not the paths
+
+
 def test_sum_mode_matches_mean(oracle):
     sc = scenes.cornell_box()
     orc = oracle.Scene(*sc.oracle_args())

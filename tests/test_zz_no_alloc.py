@@ -113,3 +113,67 @@ def test_static_entry_point_launches_a_recorded_run_through_the_static_workspace
         rr.close()
     assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
     dev.close()
+
+
+def test_static_entry_point_leaves_a_recorded_run_it_cannot_hold(ctx):
+    """A recorded run whose single dispatch does not fit the static array is refused
+    by ptc_render_static before anything is dropped: PTC_E_LIMIT, the run stays
+    recorded, the sample count still includes it, and ptc_film_flush launches it
+    through the context's own workspace."""
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(ctx, sc)
+    w, h = 1600, 1200  # 1.92 M paths per dispatch: beyond the 64 MiB array
+    cam = R.default_camera(w, h)
+    ref = R.RenderResources(ctx, w, h, dev)
+    ref.integrator, ref.max_depth = R.INTEGRATOR_WAVEFRONT, 4
+    ref.render(cam, frame=0, n_frames=2)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.integrator, rr.max_depth = R.INTEGRATOR_WAVEFRONT, 4
+    rr.render(cam, frame=0, deferred=True)
+    rr.render(cam, frame=1, deferred=True)
+    with pytest.raises(R.PtcError, match="static array holds"):
+        rr.render(cam, frame=2, static=True)
+    assert rr.sample_count == 2  # still recorded
+    rr.flush()
+    assert rr.sample_count == 2
+    assert np.array_equal(rr.read_accum().view(np.uint32), ref.read_accum().view(np.uint32))
+    rr.close()
+    ref.close()
+    dev.close()
+
+
+def test_static_entry_point_allocates_no_device_memory(ctx):
+    """Free device memory does not move across ptc_render_static calls (every
+    integrator, and a recorded run launched through the static workspace) on a
+    context that has never grown a workspace of its own."""
+    torch = pytest.importorskip("torch")
+    own = R.create_context(0)
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(own, sc)
+    w, h = 160, 96
+    cam = R.default_camera(w, h)
+    rr = R.RenderResources(own, w, h, dev)
+    rr.max_depth = 5
+    frame = 0
+    for integrator in (R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM):  # kernels loaded
+        rr.integrator = integrator
+        rr.render(cam, frame=frame, n_frames=2, static=True)
+        frame += 2
+    own.synchronize()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for integrator in (R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM, R.INTEGRATOR_AUTO):
+        rr.integrator = integrator
+        for spf in (1, 2):
+            rr.render(cam, frame=frame, samples_per_frame=spf, n_frames=3, static=True)
+            frame += 3
+        rr.render(cam, frame=frame, deferred=True)
+        rr.render(cam, frame=frame + 1, deferred=True)
+        rr.render(cam, frame=frame + 2, static=True)  # launches the recorded run through the static workspace
+        frame += 3
+        assert torch.cuda.mem_get_info(0)[0] == free0
+    own.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] == free0
+    rr.close()
+    dev.close()
+    own.close()

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Counter profiles of the configurations whose step the persistent launch dominates:
+# the reference's four-instance table (flattened and two-level), the mesh inside
+# the Cornell box at 4K, the Cornell box alone.
+# Usage (on the GPU box): bash tools/profile_r03.sh [tag]
+set -u
+TAG=${1:-r03}
+one() { # label, bench args...
+  local label=$1; shift
+  bash tools/profile_pmc.sh ${TAG}_$label "$@" &&
+  python3 tools/summarize_pmc.py gpurun_out/${TAG}_$label gpurun_out/${TAG}_$label/summary.json > /dev/null &&
+  find gpurun_out/${TAG}_$label -name '*.csv' ! -name '*kernel_stats.csv' -delete
+}
+one ref4 --scene ref4 --spp-per-step 128 &&
+one ref4_two_level --scene ref4 --spp-per-step 128 --two-level &&
+one c5_4k --scene c5 --width 3840 --height 2160 --spp-per-step 64 &&
+one cornell1024 --scene cornell --width 1024 --height 1024 --max-depth 8
