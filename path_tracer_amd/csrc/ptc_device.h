@@ -965,14 +965,13 @@ PTC_DEV Hit trace_closest_interleaved(const DScene &S, vec3 o, vec3 d, float tma
 }
 
 // Two-level scenes, the structure of the reference's TLAS over one BLAS per
-// mesh (src/renderer.cpp:1044-1281): the instances are walked in order; a ray
-// that meets an instance's world box is taken to object space with the
-// instance's w2o matrix (origin as a point, direction as a vector and not
-// re-normalised, so t keeps its meaning) and traverses the mesh's own tree
-// with the current best t as its limit. Instances later in the list have
-// larger flattened indices, so the strict t < limit of the triangle test is
-// exactly the (t, flat) order of the hit definition. The list is linear: the
-// reference's instance counts are a handful.
+// mesh (src/renderer.cpp:1044-1281): a ray that meets an instance's world box
+// is taken to object space with the instance's w2o matrix (origin as a point,
+// direction as a vector and not re-normalised, so t keeps its meaning) and
+// traverses the mesh's own tree with the current best t as its limit (see
+// instance_t_limit() for ties between instances). The instances sit in a tree
+// over their boxes; a ray takes the ones it can meet nearest first when a
+// short list holds them, in the tree's order otherwise.
 // Conservative slab test of a ray against a padded box.
 PTC_DEV bool ray_meets_box(float4 lo, float4 hi, vec3 o, vec3 d, float best_t)
 {
@@ -983,6 +982,22 @@ PTC_DEV bool ray_meets_box(float4 lo, float4 hi, vec3 o, vec3 d, float best_t)
     const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
     const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
     const float slack = (__builtin_fabsf(tn) + __builtin_fabsf(tf)) * kSlabSlack;
+    return tn - slack <= tf + slack && tf + slack >= 0.0f && tn - slack <= best_t * kTLimitPad;
+}
+
+// The same test with the reciprocal direction at hand (a caller that tests many
+// boxes against one ray divides once); *entry receives the conservative entry
+// distance, clamped to 0 for a ray that starts inside the box.
+PTC_DEV bool ray_meets_box_inv(float4 lo, float4 hi, vec3 o, float idx, float idy, float idz, float best_t,
+                               float *entry)
+{
+    const float ax = (lo.x - o.x) * idx, bx = (hi.x - o.x) * idx;
+    const float ay = (lo.y - o.y) * idy, by = (hi.y - o.y) * idy;
+    const float az = (lo.z - o.z) * idz, bz = (hi.z - o.z) * idz;
+    const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
+    const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
+    const float slack = (__builtin_fabsf(tn) + __builtin_fabsf(tf)) * kSlabSlack;
+    *entry = fmax_(tn - slack, 0.0f);
     return tn - slack <= tf + slack && tf + slack >= 0.0f && tn - slack <= best_t * kTLimitPad;
 }
 
@@ -1010,6 +1025,55 @@ PTC_DEV uint32_t next_instance(const DScene &S, uint32_t &pos, vec3 o, vec3 d, f
     return kNoInstance;
 }
 
+// The instances a ray can meet, nearest first: one walk of the whole instance
+// tree that keeps the leaves whose boxes the ray meets, ordered by the distance
+// at which it enters them (a ray that starts inside several boxes takes them in
+// tree order). Up to four leaves fit the list, one byte each, the nearest in
+// the low byte, 0xff = no entry; a fifth leaf or a leaf number beyond 254 makes
+// the function return false, and the caller walks the tree in its own order
+// with next_instance() instead. Visiting near instances first lets the hit
+// found there cull the far ones' boxes (the caller tests a leaf's box again,
+// against its best hit by then, before it enters the instance).
+constexpr uint32_t kNoCandidates = 0xffffffffu;
+PTC_DEV bool nearest_instances(const DScene &S, vec3 o, vec3 d, float tmax, uint32_t &list)
+{
+    const float idx = 1.0f / clamp_dir(d.x), idy = 1.0f / clamp_dir(d.y), idz = 1.0f / clamp_dir(d.z);
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f; // entry distances of the listed leaves
+    uint32_t n = 0u;
+    list = kNoCandidates;
+    bool fits = true;
+    for (uint32_t pos = 0u; pos < S.n_inst_nodes;)
+    {
+        const float4 lo = S.inst_box[2u * pos], hi = S.inst_box[2u * pos + 1u];
+        float t;
+        if (!ray_meets_box_inv(lo, hi, o, idx, idy, idz, tmax, &t))
+        {
+            pos = __float_as_uint(lo.w);
+            continue;
+        }
+        if (__float_as_uint(hi.w) != kNoInstance)
+        {
+            if (n == 4u || pos >= 255u)
+            {
+                fits = false;
+                break;
+            }
+            // insert behind every entry that is not farther (stable for equal distances)
+            const uint32_t at = (n > 0u && t0 <= t ? 1u : 0u) + (n > 1u && t1 <= t ? 1u : 0u) + (n > 2u && t2 <= t ? 1u : 0u);
+            const uint32_t keep = at == 0u ? 0u : (0xffffffffu >> (32u - 8u * at));
+            list = (list & keep) | (pos << (8u * at)) | ((list & ~keep) << 8);
+            t3 = at <= 2u ? t2 : t;
+            t2 = at <= 1u ? t1 : (at == 2u ? t : t2);
+            t1 = at == 0u ? t0 : (at == 1u ? t : t1);
+            t0 = at == 0u ? t : t0;
+            ++n;
+        }
+        ++pos;
+    }
+    (void)t3;
+    return fits;
+}
+
 // The t limit of a ray inside instance inst. Instances are met in the tree's
 // order, not in index order, so the (t, instance, primitive) order of the hit
 // definition takes a rule: a hit at exactly the best t wins against a best hit
@@ -1026,10 +1090,40 @@ PTC_DEV Hit trace_two_level(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *
                             TraceCounters *ctr)
 {
     Hit best = no_hit(tmax);
-    uint32_t pos = ray_is_finite(o, d) ? 0u : S.n_inst_nodes; // a non-finite ray meets no instance
-    for (uint32_t i = next_instance(S, pos, o, d, best.t); i != kNoInstance;
-         i = next_instance(S, pos, o, d, best.t))
+    // The instances the ray can meet, nearest first, so that a hit in a near one
+    // rules out the boxes of the far ones; when the list cannot hold them, the
+    // instance tree in its own order.
+    uint32_t list = kNoCandidates, pos = S.n_inst_nodes; // (a non-finite ray meets no instance)
+    bool listed = true;
+    if (ray_is_finite(o, d) && !nearest_instances(S, o, d, tmax, list))
     {
+        listed = false;
+        pos = 0u;
+    }
+    for (;;)
+    {
+        uint32_t i = kNoInstance;
+        if (listed)
+        {
+            while (list != kNoCandidates && i == kNoInstance)
+            {
+                const uint32_t leaf = list & 0xffu;
+                list = (list >> 8) | 0xff000000u;
+                const float4 lo = S.inst_box[2u * leaf], hi = S.inst_box[2u * leaf + 1u];
+                if (ray_meets_box(lo, hi, o, d, best.t))
+                {
+                    i = __float_as_uint(hi.w);
+                }
+            }
+        }
+        else
+        {
+            i = next_instance(S, pos, o, d, best.t);
+        }
+        if (i == kNoInstance)
+        {
+            break;
+        }
         const DInstance *__restrict__ I = &S.instances[i];
         const vec3 ro = xform_point(I->w2o, o);
         const vec3 rd = xform_vector(I->w2o, d);

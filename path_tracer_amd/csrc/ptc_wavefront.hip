@@ -88,6 +88,9 @@ struct WfBuffers
     uint32_t *carry;
     uint32_t spf;      // samples per dispatch
     uint32_t n_pixels;
+    // Regrouped hand-over (DFrame::regroup): the launch that traces next takes its
+    // i-th work item from queue slot order[i] instead of slot i; nullptr = slot order.
+    const uint32_t *order;
 };
 
 // path id = (dispatch * spf + sample) * n_pixels + pixel. (Keeping the paths of
@@ -289,12 +292,13 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
 
 __global__ void __launch_bounds__(kBlock)
 k_wf_trace(DScene S, float tmax, WfState q, float4 *__restrict__ hit, uint2 *__restrict__ hit_ids,
-           const uint32_t *__restrict__ count)
+           const uint32_t *__restrict__ count, const uint32_t *__restrict__ order)
 {
     __shared__ uint2 s_stack[kLdsStack * kBlock];
     const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock)
     {
+        const uint32_t i = order != nullptr ? order[j] : j; // the j-th ray traced is the one of slot i
         const float4 a = q.a[i], b = q.b[i];
         const vec3 o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
         const Hit h = S.inst_box != nullptr
@@ -380,6 +384,158 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src, 
     }
 }
 
+// ---- regrouping the queue between bounces -------------------------------------
+// The paths of a queue are handed to the next tracing launch sorted by a 15-bit
+// key of their ray: the cell of the origin in a 16 x 16 x 16 grid over the scene's
+// box, along a Morton curve (high bits), and the direction's octant (low bits).
+// A counting sort in three launches, none of which needs the number of paths on
+// the host: keys and a histogram (one atomic per wave and distinct key: the queue
+// arrives in pixel order, so the lanes of a wave mostly share a key), an exclusive
+// scan of the 32,768 bins, and a scatter of the slot numbers into order[]. Paths
+// with equal keys end up in no particular order; results do not depend on it
+// (every path carries its own RNG state).
+constexpr uint32_t kRegroupBins = 1u << 15;
+
+PTC_DEV uint32_t spread4(uint32_t v) // 4 bits -> every third bit
+{
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+
+PTC_DEV uint32_t regroup_key(const DScene &S, vec3 o, vec3 d)
+{
+    float4 lo = S.box_lo, hi = S.box_hi;
+    if (S.inst_box != nullptr && S.n_inst_nodes != 0u)
+    {
+        lo = S.inst_box[0]; // the root of the instance tree: the box of all instances
+        hi = S.inst_box[1];
+    }
+    const float fx = (o.x - lo.x) / (hi.x - lo.x), fy = (o.y - lo.y) / (hi.y - lo.y), fz = (o.z - lo.z) / (hi.z - lo.z);
+    // (NaN and out-of-box origins clamp to an edge cell: any key is a valid key)
+    const uint32_t cx = (uint32_t)fmin_(fmax_(fx * 16.0f, 0.0f), 15.0f);
+    const uint32_t cy = (uint32_t)fmin_(fmax_(fy * 16.0f, 0.0f), 15.0f);
+    const uint32_t cz = (uint32_t)fmin_(fmax_(fz * 16.0f, 0.0f), 15.0f);
+    const uint32_t cell = spread4(cx) | (spread4(cy) << 1) | (spread4(cz) << 2);
+    const uint32_t oct = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+    return (cell << 3) | oct;
+}
+
+// Is slot i of the queue filled? Segmented queue (seg_cap != 0): slot i lies in
+// segment i / seg_cap, which holds fill[kFillStride * segment] paths; else the
+// queue is one run of *count paths.
+PTC_DEV bool slot_filled(uint32_t i, uint32_t seg_cap, const uint32_t *fill, const uint32_t *count)
+{
+    if (seg_cap != 0u)
+    {
+        const uint32_t seg = i / seg_cap;
+        return seg < kQueueSegments && i - seg * seg_cap < fill[kFillStride * seg];
+    }
+    return i < *count;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_regroup_keys(DScene S, WfState q, uint32_t n_slots, uint32_t seg_cap, const uint32_t *__restrict__ fill,
+               const uint32_t *__restrict__ count, uint32_t *__restrict__ keys, uint32_t *__restrict__ bins)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ((n_slots + 63u) & ~63u); i += gridDim.x * kBlock)
+    {
+        const bool valid = i < n_slots && slot_filled(i, seg_cap, fill, count);
+        uint32_t key = kRegroupBins; // (no key)
+        if (valid)
+        {
+            const float4 a = q.a[i], b = q.b[i];
+            key = regroup_key(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+            keys[i] = key;
+        }
+        // one atomic per distinct key among the wave's lanes
+        unsigned long long todo = __ballot(valid);
+        while (todo != 0ull)
+        {
+            const uint32_t k0 = __shfl(key, (int)__builtin_ctzll(todo), 64);
+            const unsigned long long same = __ballot(valid && key == k0);
+            if (lane_id() == (uint32_t)__builtin_ctzll(todo))
+            {
+                atomicAdd(&bins[k0], (uint32_t)__builtin_popcountll(same));
+            }
+            todo &= ~same;
+        }
+    }
+}
+
+// Exclusive scan of the bins (one block of 1024 threads, 32 bins each); the total
+// goes to *total_out, where the next launch reads its number of work items.
+__global__ void __launch_bounds__(1024)
+k_regroup_scan(uint32_t *__restrict__ bins, uint32_t *__restrict__ total_out)
+{
+    __shared__ uint32_t s_wave[16];
+    constexpr uint32_t kPer = kRegroupBins / 1024u;
+    uint32_t local[kPer];
+    uint32_t sum = 0u;
+    for (uint32_t k = 0; k < kPer; ++k)
+    {
+        local[k] = sum;
+        sum += bins[threadIdx.x * kPer + k];
+    }
+    // exclusive scan of the threads' sums: within the wave, then over the 16 waves
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        incl += lane >= (uint32_t)off ? up : 0u;
+    }
+    if (lane == 63u)
+    {
+        s_wave[wave] = incl;
+    }
+    __syncthreads();
+    uint32_t before = 0u;
+    for (uint32_t w = 0; w < wave; ++w)
+    {
+        before += s_wave[w];
+    }
+    const uint32_t base = before + incl - sum;
+    for (uint32_t k = 0; k < kPer; ++k)
+    {
+        bins[threadIdx.x * kPer + k] = base + local[k];
+    }
+    if (threadIdx.x == 1023u)
+    {
+        *total_out = base + sum;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_regroup_scatter(uint32_t n_slots, uint32_t seg_cap, const uint32_t *__restrict__ fill, const uint32_t *__restrict__ count,
+                  const uint32_t *__restrict__ keys, uint32_t *__restrict__ bins, uint32_t *__restrict__ order)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ((n_slots + 63u) & ~63u); i += gridDim.x * kBlock)
+    {
+        const bool valid = i < n_slots && slot_filled(i, seg_cap, fill, count);
+        const uint32_t key = valid ? keys[i] : kRegroupBins;
+        // the lanes of a wave that share a key take consecutive places, in lane
+        // order: neighbouring slots stay neighbours, so the gather through order[]
+        // reads runs of consecutive slots
+        unsigned long long todo = __ballot(valid);
+        while (todo != 0ull)
+        {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+            const uint32_t k0 = __shfl(key, (int)leader, 64);
+            const unsigned long long same = __ballot(valid && key == k0);
+            uint32_t base = 0u;
+            if (lane_id() == leader)
+            {
+                base = atomicAdd(&bins[k0], (uint32_t)__builtin_popcountll(same));
+            }
+            base = __shfl(base, (int)leader, 64);
+            if (valid && key == k0)
+            {
+                order[base + (uint32_t)__builtin_popcountll(same & ((1ull << lane_id()) - 1ull))] = i;
+            }
+            todo &= ~same;
+        }
+    }
+}
+
 // One triangle test of the persistent kernel. In a two-level scene the records
 // of a mesh's tree carry no instance: a test that improved the hit marks it
 // with the instance the lane is in.
@@ -443,6 +599,9 @@ PTC_DEV void drain_tri_test(const DScene &S, const RayCtx &R, uint32_t tri_index
 // spilling loop invariants to scratch (43.9 ms and worse).
 // (Camera items keep three more words per lane in LDS, which leaves room for 4.)
 constexpr int kDrainBlock = 256, kDrainLds = 6;
+#ifndef PTC_INST_MIN
+#define PTC_INST_MIN 12
+#endif
 constexpr int drain_waves(bool camera)
 {
     return camera ? 4 : 5;
@@ -488,13 +647,19 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // lanes with short and long traversals do not wait for each other; the
     // rarer phases (pulling new paths, shading, triangle tests) run when
     // enough lanes of the wave want them, or when a lane has nothing else left.
-    constexpr uint32_t kIdle = 0u, kTrav = 1u, kShade = 2u;
+    // (two-level scenes: kInst, between two instances: the lane's traversal of one
+    // instance's tree is complete, or its ray has just started, and it waits to be
+    // taken into the next instance on its list)
+    constexpr uint32_t kIdle = 0u, kTrav = 1u, kShade = 2u, kInst = 3u;
     // lanes that must want a phase before it runs (swept with the traversal state parked in LDS: 12 to 24 lanes
     // for each of the three are within 1 % of one another on the 871k-triangle scene, 8 and 32 cost 3 to 7 %;
     // scenes whose paths are shaded more often per node visited want the shading quorum higher: 16 / 20 / 24 /
     // 32 lanes give 36.1 / 36.0 / 36.4 / 37.4 ms there, 103.2 / 101.6 / 101.4 / 105.8 with the mesh inside
     // the Cornell box, 27.3 / 25.3 / 24.8 / 24.2 on the Cornell box alone)
     constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 20u, kTriMoreMin = 16u;
+    // two-level scenes: lanes between two instances that must wait before the wave
+    // takes them into their next instances together
+    constexpr uint32_t kInstMin = PTC_INST_MIN;
     uint32_t mode = kIdle;
     constexpr uint32_t kChunk = 256u; // work items a wave reserves per atomic (64: Cornell box 17 % slower; 128, 512: within 0.5 %)
     uint32_t chunk_next = 0u, chunk_end = 0u; // this wave's reserved items not handed out yet
@@ -520,7 +685,11 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // best.instance. (Flattened scenes trace the world-space ray itself.)
     vec3 obj_o = org, obj_d = dir;
     float obj_tmax = tmax;
-    uint32_t inst = 0u, inst_pos = 0u;
+    // inst_pos == kListed: the instances the ray can meet are listed nearest first in
+    // inst_list (see nearest_instances()); otherwise the list did not hold them and
+    // inst_pos is the lane's place in the instance tree, walked in its own order
+    constexpr uint32_t kListed = 0xffffffffu;
+    uint32_t inst = 0u, inst_pos = 0u, inst_list = kNoCandidates;
     auto ray_ctx = [&]() {
         RayCtx R;
         R.o = kTwoLevel ? obj_o : org;
@@ -735,7 +904,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             else if (got)
             {
                 PathState ps;
-                const uint32_t pid = load_state(qi, i, ps);
+                const uint32_t pid = load_state(qi, B.order != nullptr ? B.order[i] : i, ps);
                 org = ps.origin;
                 dir = ps.dir;
                 store_cold(ps, pid, bounce0);
@@ -760,7 +929,13 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             const bool finite = ray_is_finite(org, dir); // a non-finite ray hits nothing and must not enter the tree
             if (kTwoLevel)
             {
-                inst_pos = finite ? 0u : S.n_inst_nodes; // the first instance is looked for below
+                // the instances the ray can meet, nearest first; the first is entered below
+                inst_pos = kListed;
+                inst_list = kNoCandidates; // (a non-finite ray meets none)
+                if (finite && !nearest_instances(S, org, dir, tmax, inst_list))
+                {
+                    inst_pos = 0u;
+                }
                 ng = make_uint2(0u, 0u);
             }
             else
@@ -770,31 +945,63 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             }
             tg = make_uint2(0u, 0u);
             sp = 0;
-            mode = kTrav;
+            mode = kTwoLevel ? kInst : kTrav;
         }
         if (exhausted && __ballot(mode != kIdle) == 0ull)
         {
             break;
+        }
+        // ---- two-level scenes: lanes between two instances enter their next one.
+        // Finding it and taking the ray to its object space (a box test or a few,
+        // the instance's matrix, three divisions) is the heavy step of such a
+        // scene; run whenever one lane wanted it, it kept the other 63 waiting
+        // once or twice per loop iteration. So the lanes wait for company, as they
+        // do for shading: the step runs when enough of them wait, right after a
+        // shading or pull phase (the rays started there all need their first
+        // instance), or when no lane of the wave is traversing.
+        if (kTwoLevel)
+        {
+            const unsigned long long waiting = __ballot(mode == kInst);
+            const uint32_t n_waiting = (uint32_t)__builtin_popcountll(waiting);
+            if (n_waiting != 0u && (n_waiting >= kInstMin || __ballot(start) != 0ull || __ballot(mode == kTrav) == 0ull) &&
+                mode == kInst)
+            {
+                uint32_t next = kNoInstance;
+                if (inst_pos == kListed)
+                {
+                    while (inst_list != kNoCandidates)
+                    {
+                        const uint32_t leaf = inst_list & 0xffu;
+                        inst_list = (inst_list >> 8) | 0xff000000u;
+                        const float4 lo = S.inst_box[2u * leaf], hi = S.inst_box[2u * leaf + 1u];
+                        if (ray_meets_box(lo, hi, org, dir, best.t)) // again: the best hit may rule the box out by now
+                        {
+                            next = __float_as_uint(hi.w);
+                            break;
+                        }
+                    }
+                }
+                else
+                {
+                    next = next_instance(S, inst_pos, org, dir, best.t);
+                }
+                mode = kShade;
+                if (next != kNoInstance)
+                {
+                    inst = next;
+                    const DInstance *__restrict__ I = &S.instances[inst];
+                    set_ray(xform_point(I->w2o, org), xform_vector(I->w2o, dir), instance_t_limit(best, inst));
+                    ng = make_uint2(I->blas_root, 0x80000000u);
+                    mode = kTrav;
+                }
+            }
         }
         // ---- out of local work: pop the stack, or the traversal is complete
         if (mode == kTrav && !(ng.y & kNodeBits) && tg.y == 0u)
         {
             if (sp == 0)
             {
-                mode = kShade;
-                if (kTwoLevel)
-                {
-                    // on to the next instance whose world box the ray meets
-                    const uint32_t next = next_instance(S, inst_pos, org, dir, best.t);
-                    if (next != kNoInstance)
-                    {
-                        inst = next;
-                        const DInstance *__restrict__ I = &S.instances[inst];
-                        set_ray(xform_point(I->w2o, org), xform_vector(I->w2o, dir), instance_t_limit(best, inst));
-                        ng = make_uint2(I->blas_root, 0x80000000u);
-                        mode = kTrav;
-                    }
-                }
+                mode = kTwoLevel ? kInst : kShade; // (two-level: on to the next instance, above, in a later iteration)
             }
             else
             {
@@ -1079,14 +1286,18 @@ size_t queue_slots(uint32_t width, uint32_t height, uint32_t max_batch, bool str
 // queue and the hit records; the default, the persistent launch right after the
 // first bounce, needs one queue: 76 bytes per path instead of 156, a little more
 // where the film is not whole 32x32-pixel groups)
+// (regroup: the sorted hand-over takes a key and a place in the order per queue
+// slot, 8 bytes, and the bins of the counting sort)
 size_t workspace_bytes(uint32_t width, uint32_t height, uint32_t spf, uint32_t max_batch, uint32_t max_depth,
-                       bool stream, bool pairs)
+                       bool stream, bool pairs, bool regroup)
 {
     const size_t cap = (size_t)width * height * max_batch;
     const size_t qcap = queue_slots(width, height, max_batch, stream, pairs), pcap = pairs && !stream ? cap : 1;
+    const size_t rcap = regroup && !stream ? qcap : 0;
     return (align256(qcap * 16) * 3 + align256(qcap * 8)) + (align256(pcap * 16) * 3 + align256(pcap * 8)) +
            align256(pcap * 16) + align256(pcap * 8) + align256(cap * spf * 16) +
-           align256(counter_words(max_depth) * 4) + align256(qcap * 4);
+           align256(counter_words(max_depth) * 4) + align256(qcap * 4) +
+           (rcap ? 2 * align256(rcap * 4) + align256((size_t)kRegroupBins * 4) : 0);
 }
 
 } // namespace
@@ -1139,7 +1350,7 @@ int plan_wavefront(const DFrame &F0, bool stream, bool static_scratch, Wavefront
         }
     }
     auto bytes_for = [&](uint32_t batch) {
-        return workspace_bytes(F0.width, F0.height, spf, batch, F0.max_depth, stream, pairs);
+        return workspace_bytes(F0.width, F0.height, spf, batch, F0.max_depth, stream, pairs, F0.regroup != 0u);
     };
     if (static_scratch)
     {
@@ -1263,6 +1474,28 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     B.carry = spf > 1u && !stream ? carry : nullptr;
     B.spf = spf;
     B.n_pixels = n_pixels;
+    B.order = nullptr;
+    const bool regroup = F0.regroup != 0u && !stream;
+    uint32_t *rg_keys = nullptr, *rg_order = nullptr, *rg_bins = nullptr;
+    if (regroup)
+    {
+        rg_keys = reinterpret_cast<uint32_t *>(take(qcap * 4));
+        rg_order = reinterpret_cast<uint32_t *>(take(qcap * 4));
+        rg_bins = reinterpret_cast<uint32_t *>(take((size_t)kRegroupBins * 4));
+    }
+    // Sorts the filled slots of queue `which` (its first n_slots slots; segmented
+    // when seg_cap != 0, else one run of *count paths) into rg_order and leaves
+    // their number in *total_out.
+    auto regroup_queue = [&](int which, size_t n_slots, uint32_t seg_cap, const uint32_t *count, uint32_t *total_out) -> int {
+        PTC_HIP_CHECK(hipMemsetAsync(rg_bins, 0, (size_t)kRegroupBins * 4, st));
+        const uint32_t blocks = (uint32_t)std::min<size_t>((n_slots + kBlock - 1) / kBlock, (size_t)ctx->n_cus * 32u);
+        k_regroup_keys<<<std::max(blocks, 1u), kBlock, 0, st>>>(scene->d, B.q[which], (uint32_t)n_slots, seg_cap, B.fill, count,
+                                                               rg_keys, rg_bins);
+        k_regroup_scan<<<1, 1024, 0, st>>>(rg_bins, total_out);
+        k_regroup_scatter<<<std::max(blocks, 1u), kBlock, 0, st>>>((uint32_t)n_slots, seg_cap, B.fill, count, rg_keys, rg_bins,
+                                                                  rg_order);
+        return PTC_OK;
+    };
 
     const uint32_t persistent_blocks = (uint32_t)ctx->n_cus * 6u;
     uint32_t sample_count = F0.sample_count;
@@ -1325,14 +1558,37 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
             {
                 PhaseTimer timer(ctx, PTC_PHASE_BOUNCE);
                 const int src = (int)(b & 1u); // the primary pass writes set 1
-                k_wf_trace<<<blocks, kBlock, 0, st>>>(scene->d, F0.tmax, B.q[src], B.hit, B.hit_ids, B.counts + b);
+                if (regroup)
+                {
+                    if (const int rc = regroup_queue(src, n_paths, 0u, B.counts + b, B.counts + b); rc != PTC_OK)
+                    {
+                        return rc;
+                    }
+                }
+                k_wf_trace<<<blocks, kBlock, 0, st>>>(scene->d, F0.tmax, B.q[src], B.hit, B.hit_ids, B.counts + b,
+                                                      regroup ? rg_order : nullptr);
                 k_wf_shade<<<std::max(1u, blocks / (kShadeBlock / kBlock)), kShadeBlock, 0, st>>>(scene->d, B, b, F0.max_depth, src, F0.debug_view);
             }
             // whatever is still alive runs to its end in one persistent launch
             if (drain_b < F0.max_depth)
             {
                 PhaseTimer timer(ctx, PTC_PHASE_DRAIN);
-                launch_drain<false>(ctx, scene, F0, B, drain_b, (int)(drain_b & 1u), 0u, 0u, 0u, n_paths);
+                WfBuffers D = B;
+                if (regroup)
+                {
+                    // (timed with the launch it serves) the sorted order turns the queue into one run of
+                    // counts[drain_b] work items, whatever shape it was filled in
+                    const size_t n_slots = B.seg_cap != 0u ? (size_t)kQueueSegments * B.seg_cap : n_paths;
+                    if (const int rc = regroup_queue((int)(drain_b & 1u), n_slots, B.seg_cap, B.counts + drain_b,
+                                                     B.counts + drain_b);
+                        rc != PTC_OK)
+                    {
+                        return rc;
+                    }
+                    D.seg_cap = 0u;
+                    D.order = rg_order;
+                }
+                launch_drain<false>(ctx, scene, F0, D, drain_b, (int)(drain_b & 1u), 0u, 0u, 0u, n_paths);
             }
             k_wf_stats<<<1, 64, 0, st>>>(B.counts, n_paths, F0.max_depth, drain_b, ctx->d_stats);
         }

@@ -12,6 +12,10 @@ import glob
 import json
 import os
 import shutil
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402  (the build a profile belongs to)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("src")
@@ -23,6 +27,8 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=256)
 ap.add_argument("--max-depth", type=int, default=32)
 ap.add_argument("--cus", type=int, default=256)
+ap.add_argument("--two-level", action="store_true")
+ap.add_argument("--regroup", action="store_true")
 a = ap.parse_args()
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,12 +50,15 @@ for symbol, short in (("k_wf_drain", "drain"), ("k_wf_primary", "primary"), ("k_
     cycles = (k.get("GRBM_GUI_ACTIVE_per_dispatch") or 0.0) / 8.0
     entry = {
         "scene": a.scene, "width": a.width, "height": a.height, "spp_per_step": a.spp, "max_depth": a.max_depth,
+        "two_level": a.two_level, "regroup": a.regroup, "kernel_source_hash": kernel_source_hash(),
         "kernel": short, "kernel_symbol": symbol, "mean_launch_us": k["mean_us"],
         "clock_ghz": round(cycles / (k["mean_us"] * 1e3), 3) if cycles else None,
         "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
         # FETCH_SIZE tallies the 128-byte fabric requests of 16-byte-per-lane loads at 64 bytes on gfx950
         "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
         "l2_hit_rate": round(k["TCC_HIT_sum_per_dispatch"] / k["TCC_REQ_sum_per_dispatch"], 4),
+        # share of the vector L1's line accesses that it served itself
+        "l1_hit_rate": round(1.0 - k["TCP_TCC_READ_REQ_sum_per_dispatch"] / k["TCP_TOTAL_CACHE_ACCESSES_sum_per_dispatch"], 4),
         # busy cycles summed over the CUs' texture-data / texture-address units against CUs x kernel cycles
         "td_busy": round(k["TD_TD_BUSY_sum_per_dispatch"] / (a.cus * cycles), 4) if cycles else None,
         "ta_busy": round(k["TA_TA_BUSY_sum_per_dispatch"] / (a.cus * cycles), 4) if cycles else None,
@@ -64,8 +73,9 @@ for symbol, short in (("k_wf_drain", "drain"), ("k_wf_primary", "primary"), ("k_
                   "L2's memory side and include Infinity-Cache hits: traffic beyond L2, an upper bound on HBM traffic",
         "source": f"profiles/{summary_name}",
     }
-    index = [e for e in index if (e["scene"], e["width"], e["height"], e["spp_per_step"], e["max_depth"], e["kernel"]) !=
-             (a.scene, a.width, a.height, a.spp, a.max_depth, short)]
+    index = [e for e in index if (e["scene"], e["width"], e["height"], e["spp_per_step"], e["max_depth"], e["kernel"],
+                                  bool(e.get("two_level")), bool(e.get("regroup"))) !=
+             (a.scene, a.width, a.height, a.spp, a.max_depth, short, a.two_level, a.regroup)]
     index.append(entry)
     print(json.dumps(entry, indent=1))
 json.dump(index, open(index_path, "w"), indent=1)
