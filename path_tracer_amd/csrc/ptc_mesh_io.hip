@@ -620,7 +620,15 @@ struct PositionIndex
             return;
         }
         const double inv = 1.0 / (double)radius;
-        auto cell_of = [&](V3 v) { return Cell {(int64_t)std::floor(v.x * inv), (int64_t)std::floor(v.y * inv), (int64_t)std::floor(v.z * inv)}; };
+        // (cell numbers are held within +-2^62: coordinates that large against this radius -- file
+        // coordinates kept with PTC_IMPORT_NO_NORMALIZE -- share the outermost cells, which costs time,
+        // not correctness, and neither the cast nor the neighbour offsets below can overflow)
+        auto cell_axis = [&](float v) {
+            const double c = std::floor((double)v * inv);
+            constexpr double kEdge = 4611686018427387904.0; // 2^62
+            return (int64_t)std::max(-kEdge, std::min(kEdge, c));
+        };
+        auto cell_of = [&](V3 v) { return Cell {cell_axis(v.x), cell_axis(v.y), cell_axis(v.z)}; };
         std::unordered_map<Cell, std::vector<uint32_t>, CellHash> grid;
         grid.reserve(unique.size());
         for (uint32_t u = 0; u < unique.size(); ++u)
@@ -1058,6 +1066,22 @@ extern "C" int ptc_mesh_file_open(const char *file_name, const ptc_import_option
         else
         {
             throw ParseError {"No suitable reader found for the file format of file \"" + name + "\"."};
+        }
+        // A NaN or an infinity among the coordinates (a binary PLY can carry any bit
+        // pattern) would poison the bounding box, the smoothing and joining grids and
+        // finally the tree: such a file is refused here.
+        for (const RawMesh &m : raw)
+        {
+            for (const std::vector<V3> *list : {&m.positions, &m.normals})
+            {
+                for (const V3 &v : *list)
+                {
+                    if (!std::isfinite(v.x) || !std::isfinite(v.y) || !std::isfinite(v.z))
+                    {
+                        throw ParseError {"Non-finite vertex coordinate or normal in file \"" + name + "\"."};
+                    }
+                }
+            }
         }
         // PreTransformVertices with AI_CONFIG_PP_PTV_NORMALIZE: the bounding box of
         // the whole scene goes to [-1, 1] along its longest axis, centred

@@ -226,6 +226,25 @@ int main(int argc, char **argv)
                                                "property float z\nelement face 99999999999999999999\n"
                                                "property list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n")) == -1,
            "PLY with an absurd face count is refused");
+    // non-finite coordinates are refused; huge finite ones kept with NO_NORMALIZE import without overflow
+    for (const char *value : {"nan", "inf", "-inf"})
+    {
+        const std::string bad = std::string("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\n"
+                                            "property float z\nelement face 1\nproperty list uchar int vertex_indices\n"
+                                            "end_header\n0 0 0\n1 ") + value + " 0\n0 1 0\n3 0 1 2\n";
+        expect(import_count(write_file("nonfinite.ply", bad)) == -1, "PLY with a non-finite coordinate is refused");
+        const std::string bad_obj = std::string("v 0 0 0\nv 1 0 ") + value + "\nv 0 1 0\nf 1 2 3\n";
+        expect(import_count(write_file("nonfinite.obj", bad_obj)) == -1, "OBJ with a non-finite coordinate is refused");
+    }
+    {
+        ptc_import_options keep {};
+        keep.flags = PTC_IMPORT_NO_NORMALIZE;
+        const std::string far = "ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\n"
+                                "property float z\nelement face 2\nproperty list uchar int vertex_indices\n"
+                                "end_header\n1e30 0 0\n-1e30 1e30 0\n0 -1e30 3e38\n1e30 1e30 1e30\n3 0 1 2\n3 1 2 3\n";
+        expect(import_count(write_file("far.ply", far), &keep) == 2, "PLY with coordinates of 1e30 kept as they are");
+        expect(import_count(write_file("far.ply", far)) == 2, "the same normalised to [-1, 1]");
+    }
     for (int rle = 0; rle < 2; ++rle)
     {
         const std::string hdr = make_hdr(rle != 0);

@@ -53,6 +53,7 @@ def test_random_call_sequences_equal_one_by_one_megakernel_dispatches(ctx, seed)
                 got.integrator = QUEUE_INTEGRATORS[int(rng.integers(0, 3))]
                 # sometimes a bound that cuts the call (or the recorded run) into several batches
                 got.max_paths_in_flight = int(rng.choice([0, w * h * spf, 3 * w * h * spf + 1]))
+                got.regroup = int(rng.integers(0, 2))  # the queue handed over sorted or as filled: the same film
                 got.render(cam, frame=frame, samples_per_frame=spf, n_frames=n_frames,
                            static=mode == "static", deferred=mode == "deferred")
                 for k in range(n_frames):

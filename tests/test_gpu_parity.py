@@ -164,6 +164,36 @@ def test_bounce_count_debug_view_bit_exact(scene_pair, ctx, oracle, integrator, 
     rr.close()
 
 
+@pytest.mark.parametrize("two_level", [False, True], ids=["flattened", "two_level"])
+@pytest.mark.parametrize("spf,n_frames,wavefront_bounces,static", [(1, 3, 0, False), (2, 2, 0, False), (1, 20, 0, False),
+                                                                  (1, 5, 2, False), (2, 17, 3, False), (1, 4, 0, True)])
+def test_regrouped_hand_over_bit_exact(ctx, oracle, two_level, spf, n_frames, wavefront_bounces, static):
+    """ptc_render_params.regroup: the paths that survive a bounce are handed to
+    the next tracing launch sorted by the cell of their ray's origin and its
+    octant. Every path carries its RNG state, so the film does not change: equal
+    to the oracle's bit for bit, with the persistent launch right after the
+    first bounce, with bounces as launch pairs before it, and through the static
+    workspace."""
+    sc = scenes.ref4_scene(scenes.knot_mesh(nu=48, nv=12), scenes.procedural_sky(64, 32))
+    dev = R.DeviceScene(ctx, sc, two_level=two_level)
+    orc = oracle.Scene(*sc.oracle_args(), two_level=two_level)
+    w, h = 72, 40
+    cam = R.default_camera(w, h)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.max_depth, rr.integrator, rr.regroup, rr.wavefront_bounces = 7, R.INTEGRATOR_WAVEFRONT, 1, wavefront_bounces
+    ctx.reset_stats()
+    rr.render(cam, frame=2, samples_per_frame=spf, n_frames=n_frames, static=static)
+    rr.render(cam, frame=2 + n_frames, samples_per_frame=spf, n_frames=1, static=static)
+    acc, img, rays = rr.read_accum(), rr.read_rgba8(), ctx.stats().rays
+    push = oracle.make_push(cam.as_dict(), frame=2, samples_per_frame=spf)
+    ref_acc, ref_img, st = orc.render(push, w, h, n_frames=n_frames + 1, max_depth=7, use_bvh=not two_level)
+    assert np.array_equal(_bits(acc), _bits(ref_acc))
+    assert np.array_equal(img, ref_img)
+    assert rays == st.rays
+    rr.close()
+    dev.close()
+
+
 @pytest.mark.parametrize("spf,n_frames", [(1, 40), (1, 70), (2, 33)])
 def test_large_batches_bit_exact(ctx, oracle, spf, n_frames):
     """Batches of 32 and more dispatches take the primary pass's other mapping

@@ -1,2 +1,8 @@
-timeout -k 10 600 python -u -m pytest tests/test_gpu_two_level.py tests/test_gpu_fuzz.py tests/test_gpu_api_fuzz.py tests/test_gpu_scale.py -x -q --timeout 300 --timeout-method thread > gpurun_out/t2.log 2>&1; rc=$?; tail -5 gpurun_out/t2.log; [ $rc -eq 0 ] || exit $rc
-AB_VARIANTS="b e" bash tools/ab.sh --scene ref4 --spp-per-step 128 --two-level > gpurun_out/ab_tl2.log 2>&1; cat gpurun_out/ab_tl2.log
+AB_VARIANTS="a f" bash tools/ab.sh --scene ref4 --spp-per-step 128 --regroup | head -4
+AB_VARIANTS="a f" bash tools/ab.sh --regroup | head -4
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+run() { timeout -k 10 300 $B "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', round(d['value'],1), d['roofline']['phase_ms_per_step'])" || exit 1; }
+for wb in 1 2; do for rg in "" "--regroup"; do
+run --scene ref4 --spp-per-step 128 --wavefront-bounces $wb $rg
+run --scene c5 --width 3840 --height 2160 --spp-per-step 64 --wavefront-bounces $wb $rg
+done; done
