@@ -480,7 +480,9 @@ void ptc_mesh_file_close(ptc_mesh_file *file);
 /* Element-wise evaluation of the device math primitives the kernels use, so
  * a checker can compare them with its own: fn 0 sincos(a) -> out, out2;
  * 1 log(a); 2 acos(a); 3 atan2(a, b); 4 a / b; 5 sqrt(a);
- * 6 (float)(uint32 bits of a) * 2^-32. Host pointers, n floats each. */
+ * 6 (float)(uint32 bits of a) * 2^-32; 7 zeros with the signs of sin(a) and
+ * cos(a) as the zero-aperture camera path derives them without evaluating
+ * either (a >= 0) -> out, out2. Host pointers, n floats each. */
 int ptc_math_eval(ptc_context *ctx, int fn, const float *a, const float *b,
                   float *out, float *out2, size_t n);
 

@@ -696,7 +696,7 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
     }
     S->info.n_bvh_triangles = (uint32_t)(S->d_inst_box ? nt : total);
     S->info.device_bytes = (uint64_t)S->info.n_nodes * 80 + (uint64_t)(S->d_inst_box ? nt : total) * 48 + nv * 24 +
-                           nt * (12 + 80) + (S->d_inst_box ? n_instances * 32 : 0) +
+                           nt * (12 + 80) + (S->d_inst_box ? (uint64_t)n_instances * 96 : 0) +
                            n_instances * sizeof(DInstance) +
                            (S->d_env ? (uint64_t)S->d.env_w * S->d.env_h * 16 : 0);
     *out = S;

@@ -1696,6 +1696,9 @@ int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &
     {
         tree.resize(2, make_float4(0.0f, 0.0f, 0.0f, 0.0f)); // never read: n_inst_nodes is 0
     }
+    // one allocation: the tree, then the instances' boxes by instance index
+    const size_t tree_entries = tree.size();
+    tree.insert(tree.end(), boxes.begin(), boxes.end());
     if (e == hipSuccess)
     {
         e = hipMalloc(&scene->d_inst_box, tree.size() * sizeof(float4));
@@ -1721,6 +1724,7 @@ int build_two_level(ptc_context *ctx, ptc_scene *scene, std::vector<DInstance> &
     scene->d.nodes = static_cast<const uint4 *>(scene->d_nodes);
     scene->d.tris = static_cast<const float4 *>(scene->d_tris);
     scene->d.inst_box = scene->d_inst_box;
+    scene->d.inst_bounds = scene->d_inst_box + tree_entries;
     scene->info.n_nodes = total_nodes;
     scene->d.n_nodes = total_nodes;
     scene->info.bvh_depth = depth;

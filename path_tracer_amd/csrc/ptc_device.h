@@ -45,6 +45,9 @@ struct DScene
     // instance through its w2o matrix.
     const float4 *__restrict__ inst_box;
     uint32_t n_inst_nodes;
+    // two-level scenes: the same padded world boxes by instance index, two float4
+    // (lo, hi) each, for a ray that knows which instance it wants to test again
+    const float4 *__restrict__ inst_bounds;
     // flattened scenes: the (padded) box of the whole tree, for rays that start
     // outside it; lo > hi when the scene has no triangles
     float4 box_lo, box_hi;
@@ -151,10 +154,29 @@ PTC_DEV void camera_ray(const DFrame &f, uint32_t px, uint32_t py, uint32_t &rng
     const float offy = 0.5f + 0.375f * gy;
     const float uvx = 2.0f * ((float)px + offx) / (float)f.width - 1.0f;
     const float uvy = 2.0f * ((float)py + offy) / (float)f.height - 1.0f;
-    float dx, dy;
-    sample_disk(rng, dx, dy);
-    const float defx = f.aperture_radius * dx;
-    const float defy = f.aperture_radius * dy;
+    float defx, defy;
+    if (f.aperture_radius == 0.0f)
+    {
+        // The reference's default (src/camera.cpp:87): the lens sample is drawn all
+        // the same (shader.rgen:184) and multiplied by zero. What survives is the
+        // sign of each zero, which reaches the ray through sums with other zeros:
+        // the two draws and the signs of cos / sin, without the square root and
+        // the polynomials. (The disk radius sqrt(u) is +0 or positive, so a
+        // product's sign is the cosine's or the sine's; the aperture is +0 or -0.)
+        (void)random_(rng);
+        bool s_negative, c_negative;
+        sincos_signs(kTwoPi * random_(rng), s_negative, c_negative);
+        const uint32_t zero = __float_as_uint(f.aperture_radius);
+        defx = __uint_as_float(zero ^ (c_negative ? 0x80000000u : 0u));
+        defy = __uint_as_float(zero ^ (s_negative ? 0x80000000u : 0u));
+    }
+    else
+    {
+        float dx, dy;
+        sample_disk(rng, dx, dy);
+        defx = f.aperture_radius * dx;
+        defy = f.aperture_radius * dy;
+    }
     const vec3 defocus_offset = f.camera_dir_x * defx + f.camera_dir_y * defy;
     origin = f.camera_position + defocus_offset;
     vec3 t = f.camera_dir_z * f.sensor_distance;
@@ -985,6 +1007,23 @@ PTC_DEV bool ray_meets_box(float4 lo, float4 hi, vec3 o, vec3 d, float best_t)
     return tn - slack <= tf + slack && tf + slack >= 0.0f && tn - slack <= best_t * kTLimitPad;
 }
 
+// The same test with hardware reciprocals (1 ulp) instead of divisions: their
+// error, 2^-23 of each slab distance, disappears in the test's slack of 2^-18,
+// so the test stays conservative; it decides only whether an instance is
+// entered, never a hit.
+PTC_DEV bool ray_meets_box_fast(float4 lo, float4 hi, vec3 o, vec3 d, float best_t)
+{
+    const float idx = __builtin_amdgcn_rcpf(clamp_dir(d.x)), idy = __builtin_amdgcn_rcpf(clamp_dir(d.y)),
+                idz = __builtin_amdgcn_rcpf(clamp_dir(d.z));
+    const float ax = (lo.x - o.x) * idx, bx = (hi.x - o.x) * idx;
+    const float ay = (lo.y - o.y) * idy, by = (hi.y - o.y) * idy;
+    const float az = (lo.z - o.z) * idz, bz = (hi.z - o.z) * idz;
+    const float tn = fmax_(fmax_(fmin_(ax, bx), fmin_(ay, by)), fmin_(az, bz));
+    const float tf = fmin_(fmin_(fmax_(ax, bx), fmax_(ay, by)), fmax_(az, bz));
+    const float slack = (__builtin_fabsf(tn) + __builtin_fabsf(tf)) * kSlabSlack;
+    return tn - slack <= tf + slack && tf + slack >= 0.0f && tn - slack <= best_t * kTLimitPad;
+}
+
 // The same test with the reciprocal direction at hand (a caller that tests many
 // boxes against one ray divides once); *entry receives the conservative entry
 // distance, clamped to 0 for a ray that starts inside the box.
@@ -1028,12 +1067,12 @@ PTC_DEV uint32_t next_instance(const DScene &S, uint32_t &pos, vec3 o, vec3 d, f
 // The instances a ray can meet, nearest first: one walk of the whole instance
 // tree that keeps the leaves whose boxes the ray meets, ordered by the distance
 // at which it enters them (a ray that starts inside several boxes takes them in
-// tree order). Up to four leaves fit the list, one byte each, the nearest in
-// the low byte, 0xff = no entry; a fifth leaf or a leaf number beyond 254 makes
-// the function return false, and the caller walks the tree in its own order
-// with next_instance() instead. Visiting near instances first lets the hit
-// found there cull the far ones' boxes (the caller tests a leaf's box again,
-// against its best hit by then, before it enters the instance).
+// tree order). Up to four instances fit the list, one byte each, the nearest in
+// the low byte, 0xff = no entry; a fifth one or an instance index beyond 254
+// makes the function return false, and the caller walks the tree in its own
+// order with next_instance() instead. Visiting near instances first lets the
+// hit found there cull the far ones' boxes (once it has a hit, the caller tests
+// an instance's box again, S.inst_bounds, before it enters the instance).
 constexpr uint32_t kNoCandidates = 0xffffffffu;
 PTC_DEV bool nearest_instances(const DScene &S, vec3 o, vec3 d, float tmax, uint32_t &list)
 {
@@ -1053,7 +1092,8 @@ PTC_DEV bool nearest_instances(const DScene &S, vec3 o, vec3 d, float tmax, uint
         }
         if (__float_as_uint(hi.w) != kNoInstance)
         {
-            if (n == 4u || pos >= 255u)
+            const uint32_t id = __float_as_uint(hi.w);
+            if (n == 4u || id >= 255u)
             {
                 fits = false;
                 break;
@@ -1061,7 +1101,7 @@ PTC_DEV bool nearest_instances(const DScene &S, vec3 o, vec3 d, float tmax, uint
             // insert behind every entry that is not farther (stable for equal distances)
             const uint32_t at = (n > 0u && t0 <= t ? 1u : 0u) + (n > 1u && t1 <= t ? 1u : 0u) + (n > 2u && t2 <= t ? 1u : 0u);
             const uint32_t keep = at == 0u ? 0u : (0xffffffffu >> (32u - 8u * at));
-            list = (list & keep) | (pos << (8u * at)) | ((list & ~keep) << 8);
+            list = (list & keep) | (id << (8u * at)) | ((list & ~keep) << 8);
             t3 = at <= 2u ? t2 : t;
             t2 = at <= 1u ? t1 : (at == 2u ? t : t2);
             t1 = at == 0u ? t0 : (at == 1u ? t : t1);
@@ -1107,12 +1147,12 @@ PTC_DEV Hit trace_two_level(const DScene &S, vec3 o, vec3 d, float tmax, uint2 *
         {
             while (list != kNoCandidates && i == kNoInstance)
             {
-                const uint32_t leaf = list & 0xffu;
+                const uint32_t id = list & 0xffu;
                 list = (list >> 8) | 0xff000000u;
-                const float4 lo = S.inst_box[2u * leaf], hi = S.inst_box[2u * leaf + 1u];
-                if (ray_meets_box(lo, hi, o, d, best.t))
+                // (without a hit so far the box passes as it did when the list was made)
+                if (best.flat == kNoHit || ray_meets_box_fast(S.inst_bounds[2u * id], S.inst_bounds[2u * id + 1u], o, d, best.t))
                 {
-                    i = __float_as_uint(hi.w);
+                    i = id;
                 }
             }
         }

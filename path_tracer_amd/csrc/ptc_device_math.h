@@ -132,6 +132,24 @@ PTC_DEV void sincos_(float theta, float &s, float &c)
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// Only the signs of sincos_(theta)'s results, for theta >= 0: what is left of a
+// sine and a cosine that are multiplied by zero. The same reduction as above
+// decides them: the quadrant, and for the odd polynomial the sign of the reduced
+// argument (its value r + r * (r^2 * p) keeps r's sign; the even one is positive;
+// a reduced argument of zero is +0 for theta >= 0).
+PTC_DEV void sincos_signs(float theta, bool &s_negative, bool &c_negative)
+{
+    const float kf = __builtin_rintf(theta * 0.636619772367581343f);
+    const int k = (int)kf;
+    float r = __builtin_fmaf(kf, -1.5703125f, theta);
+    r = __builtin_fmaf(kf, -4.837512969970703125e-4f, r);
+    r = __builtin_fmaf(kf, -7.54978995489188216e-8f, r);
+    const bool r_negative = (__float_as_uint(r) >> 31) != 0u;
+    const int q = k & 3;
+    s_negative = ((q & 1) ? false : r_negative) != ((q & 2) != 0);
+    c_negative = ((q & 1) ? r_negative : false) != (((q + 1) & 2) != 0);
+}
+
 // natural log of a normal positive float
 PTC_DEV float log_(float x)
 {

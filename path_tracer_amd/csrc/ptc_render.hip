@@ -186,6 +186,15 @@ k_math_eval(int fn, const float *__restrict__ a, const float *__restrict__ b, fl
     case 3: r = atan2_(x, y); break;
     case 4: r = x / y; break;
     case 5: r = __builtin_sqrtf(x); break;
+    case 7:
+    {
+        // zeros carrying the signs sincos_signs() predicts for sin and cos of x
+        bool sn, cn;
+        sincos_signs(x, sn, cn);
+        r = sn ? -0.0f : 0.0f;
+        r2 = cn ? -0.0f : 0.0f;
+        break;
+    }
     default: r = (float)__float_as_uint(x) * (1.0f / 4294967296.0f); break;
     }
     out[i] = r;

@@ -44,7 +44,7 @@ constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 // Debugging aid: cycles the persistent kernel's waves spent in each part of their loop (PTC_DRAIN_PROFILE=1).
-static __device__ unsigned long long g_drain_prof[16];
+static __device__ unsigned long long g_drain_prof[20];
 
 namespace ptc
 {
@@ -88,17 +88,22 @@ struct WfBuffers
     uint32_t *carry;
     uint32_t spf;      // samples per dispatch
     uint32_t n_pixels;
+    uint32_t per_pixel; // paths per pixel in this batch: dispatches * samples per dispatch
     // Regrouped hand-over (DFrame::regroup): the launch that traces next takes its
     // i-th work item from queue slot order[i] instead of slot i; nullptr = slot order.
     const uint32_t *order;
 };
 
-// path id = (dispatch * spf + sample) * n_pixels + pixel. (Keeping the paths of
-// one pixel next to each other instead makes the resolve pass 5x slower and
-// the stores of the primary pass no faster.)
+// path id = pixel * per_pixel + dispatch * spf + sample: the paths of a pixel lie
+// next to each other, in the order the film folds them. A wave of the primary
+// pass is one pixel with 64 dispatches, so the radiances it stores (three
+// quarters of all paths end there in an open scene) are 1 KB in a row; with the
+// dispatch as the slow index they were 64 stores a whole film apart (an all-sky
+// view, which does nothing but generate rays and store radiances, took a third
+// longer). The resolve pass reads the rows through LDS (see k_wf_resolve).
 PTC_DEV uint32_t path_id(const WfBuffers &B, uint32_t pixel, uint32_t k, uint32_t sample)
 {
-    return (k * B.spf + sample) * B.n_pixels + pixel;
+    return pixel * B.per_pixel + k * B.spf + sample;
 }
 
 PTC_DEV void finish_path(const WfBuffers &B, uint32_t pid, vec3 L, uint32_t rng)
@@ -106,8 +111,8 @@ PTC_DEV void finish_path(const WfBuffers &B, uint32_t pid, vec3 L, uint32_t rng)
     B.radiance[pid] = make_float4(L.x, L.y, L.z, 1.0f);
     if (B.carry != nullptr)
     {
-        const uint32_t per_dispatch = B.spf * B.n_pixels;
-        B.carry[(pid / per_dispatch) * B.n_pixels + pid % B.n_pixels] = rng;
+        const uint32_t pixel = pid / B.per_pixel, k = (pid - pixel * B.per_pixel) / B.spf;
+        B.carry[k * B.n_pixels + pixel] = rng;
     }
 }
 
@@ -228,7 +233,7 @@ k_wf_primary(DScene S, DFrame F, WfBuffers B, uint32_t frame_first, uint32_t k_f
             // test spares those the visit of the root node. (A wave holds samples
             // of one pixel or of one tile, so its lanes mostly agree.)
             Hit h = no_hit(F.tmax);
-            if (kTwoLevel || ray_meets_box(S.box_lo, S.box_hi, ps.origin, ps.dir, F.tmax))
+            if (kTwoLevel || ray_meets_box_fast(S.box_lo, S.box_hi, ps.origin, ps.dir, F.tmax))
             {
                 h = trace_scene<kCount, kTwoLevel, kPrimaryLds>(S, ps.origin, ps.dir, F.tmax, s_stack + threadIdx.x,
                                                                 kBlock, &ctr);
@@ -739,6 +744,9 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     const unsigned long long t_begin = t_prev;
     unsigned long long t_exhausted = 0ull; // kProfile: when the wave found the queue empty
     uint32_t ray_iters = 0u, ray_iters_max = 0u; // kProfile: loop iterations of the lane's current ray, and the most any of its rays took
+    // kProfile: stack entries this lane pushed, how many of them beyond the LDS part (to scratch memory), entries it
+    // popped from there, and its deepest stack
+    uint32_t n_push = 0u, n_push_spill = 0u, n_pop_spill = 0u, sp_max = 0u;
 #define PTC_PROF(k)                                                     \
     if (kProfile)                                                       \
     {                                                                   \
@@ -803,7 +811,7 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                     if (sample < B.spf)
                     {
                         // next sample of the same dispatch continues the RNG stream
-                        pid += B.n_pixels;
+                        pid += 1u;
                         ps = camera_path(F, PTC_WORD(9), PTC_WORD(10), ps.rng);
                         bounce = 0u;
                         start = true;
@@ -971,12 +979,13 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
                 {
                     while (inst_list != kNoCandidates)
                     {
-                        const uint32_t leaf = inst_list & 0xffu;
+                        const uint32_t id = inst_list & 0xffu;
                         inst_list = (inst_list >> 8) | 0xff000000u;
-                        const float4 lo = S.inst_box[2u * leaf], hi = S.inst_box[2u * leaf + 1u];
-                        if (ray_meets_box(lo, hi, org, dir, best.t)) // again: the best hit may rule the box out by now
+                        // once there is a hit, the box is tested again: the hit may rule it out by now
+                        if (best.flat == kNoHit ||
+                            ray_meets_box_fast(S.inst_bounds[2u * id], S.inst_bounds[2u * id + 1u], org, dir, best.t))
                         {
-                            next = __float_as_uint(hi.w);
+                            next = id;
                             break;
                         }
                     }
@@ -1005,6 +1014,10 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
             }
             else
             {
+                if (kProfile && sp > kDrainLds)
+                {
+                    ++n_pop_spill;
+                }
                 const uint2 e = stack_pop<kDrainLds>(lds, kDrainBlock, spill, sp);
                 if (e.y & kNodeBits)
                 {
@@ -1021,6 +1034,14 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
         if (mode == kTrav && (ng.y & kNodeBits))
         {
             const uint32_t node_idx = next_child(ng, octinv);
+            if (kProfile)
+            {
+                const uint32_t pushes = ((ng.y & kNodeBits) ? 1u : 0u) + (tg.y ? 1u : 0u);
+                const uint32_t in_lds = (uint32_t)sp < (uint32_t)kDrainLds ? (uint32_t)kDrainLds - (uint32_t)sp : 0u;
+                n_push += pushes;
+                n_push_spill += pushes > in_lds ? pushes - in_lds : 0u;
+                sp_max = (uint32_t)sp + pushes > sp_max ? (uint32_t)sp + pushes : sp_max;
+            }
             if (ng.y & kNodeBits)
             {
                 stack_push<kDrainLds>(lds, kDrainBlock, spill, sp, ng);
@@ -1102,6 +1123,22 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     {
         // 10: most iterations of one wave; 11: most cycles of one wave; 12: most iterations of one ray;
         atomicMax(&g_drain_prof[12], (unsigned long long)ray_iters_max);
+        // 16: stack pushes; 17: of them to scratch memory; 18: pops from scratch memory; 19: deepest stack of any lane
+        unsigned long long sums[3] = {n_push, n_push_spill, n_pop_spill};
+        for (int k = 0; k < 3; ++k)
+        {
+            for (int off = 32; off > 0; off >>= 1)
+            {
+                sums[k] += __shfl_xor(sums[k], off, 64);
+            }
+        }
+        atomicMax(&g_drain_prof[19], (unsigned long long)sp_max);
+        if (lane == 0u)
+        {
+            atomicAdd(&g_drain_prof[16], sums[0]);
+            atomicAdd(&g_drain_prof[17], sums[1]);
+            atomicAdd(&g_drain_prof[18], sums[2]);
+        }
         if (lane == 0u)
         {
             for (int k = 0; k < 10; ++k)
@@ -1124,37 +1161,65 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
 }
 
 // Per pixel: fold the batch's per-path radiances into the film in dispatch
-// order (shader.rgen:196, :202-223), then tone-map.
+// order (shader.rgen:196, :202-223), then tone-map. A lane owns a pixel (the
+// fold is sequential per pixel), but a pixel's radiances lie in a row, so lanes
+// reading their own rows would touch 64 lines per load: the block stages
+// kResolveTile entries of each of its 256 rows in LDS (8 lanes read the 128
+// contiguous bytes of one row) and every lane then takes its row's entries from
+// there. Rows are padded by one entry in LDS against bank conflicts.
+constexpr uint32_t kResolveTile = 8u; // (4: 64-byte runs, 16: half the resident blocks: the pass takes 2.4 and 2.8 ms against 1.67)
 __global__ void __launch_bounds__(kBlock)
 k_wf_resolve(DFrame F, const float4 *__restrict__ radiance, uint32_t n_disp, uint32_t spf,
              uint32_t sample_count0, float4 *__restrict__ accum, uint32_t *__restrict__ rgba8)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float4 s_tile[kBlock * (kResolveTile + 1u)];
+    const uint32_t first_pixel = blockIdx.x * kBlock, i = first_pixel + threadIdx.x;
     const uint32_t n_pixels = F.width * F.height;
-    if (i >= n_pixels)
-    {
-        return;
-    }
+    const bool inside = i < n_pixels;
     float4 avg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t sample_count = sample_count0;
-    if (sample_count > 0u)
+    if (inside && sample_count > 0u)
     {
         avg = accum[i];
     }
     // n_disp consecutive paths of this pixel; every spf of them form one dispatch
-    for (uint32_t k = 0; k < n_disp; k += spf)
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t in_dispatch = 0u;
+    for (uint32_t j0 = 0; j0 < n_disp; j0 += kResolveTile)
     {
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (uint32_t s = 0; s < spf; ++s)
+        const uint32_t n_tile = n_disp - j0 < kResolveTile ? n_disp - j0 : kResolveTile;
+        __syncthreads(); // the previous tile has been read
+        for (uint32_t r = 0; r < kResolveTile; ++r)
         {
-            const float4 r = radiance[(size_t)(k + s) * n_pixels + i];
-            acc.x += r.x;
-            acc.y += r.y;
-            acc.z += r.z;
-            acc.w += 1.0f;
+            const uint32_t l = r * kBlock + threadIdx.x, row = l / kResolveTile, e = l % kResolveTile;
+            if (first_pixel + row < n_pixels && e < n_tile)
+            {
+                s_tile[row * (kResolveTile + 1u) + e] = radiance[(size_t)(first_pixel + row) * n_disp + j0 + e];
+            }
         }
-        avg = accumulate(avg, acc, sample_count, spf, F.accumulate_sum != 0u);
-        sample_count += spf;
+        __syncthreads();
+        if (inside)
+        {
+            for (uint32_t e = 0; e < n_tile; ++e)
+            {
+                const float4 r = s_tile[threadIdx.x * (kResolveTile + 1u) + e];
+                acc.x += r.x;
+                acc.y += r.y;
+                acc.z += r.z;
+                acc.w += 1.0f;
+                if (++in_dispatch == spf)
+                {
+                    avg = accumulate(avg, acc, sample_count, spf, F.accumulate_sum != 0u);
+                    sample_count += spf;
+                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    in_dispatch = 0u;
+                }
+            }
+        }
+    }
+    if (!inside)
+    {
+        return;
     }
     accum[i] = avg;
     vec3 lin = v3(avg.x, avg.y, avg.z);
@@ -1474,6 +1539,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     B.carry = spf > 1u && !stream ? carry : nullptr;
     B.spf = spf;
     B.n_pixels = n_pixels;
+    B.per_pixel = spf; // (set per batch below)
     B.order = nullptr;
     const bool regroup = F0.regroup != 0u && !stream;
     uint32_t *rg_keys = nullptr, *rg_order = nullptr, *rg_bins = nullptr;
@@ -1503,6 +1569,7 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
     {
         const uint32_t nb = std::min(max_batch, F0.n_frames - k0);
         const uint32_t n_paths = n_pixels * nb;
+        B.per_pixel = nb * spf;
         if (stream)
         {
             // one persistent launch: camera rays are generated as lanes fall idle
@@ -1607,12 +1674,12 @@ int launch_render_wavefront(ptc_context *ctx, const ptc_scene *scene, ptc_film *
 
 // Debugging aid (not part of the public header): reads and clears the cycle
 // counters of the profiled persistent kernel (tools/drain_prof.py).
-extern "C" int ptc_debug_drain_profile(unsigned long long *out16)
+extern "C" int ptc_debug_drain_profile(unsigned long long *out20)
 {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_drain_prof), sizeof(unsigned long long) * 16) != hipSuccess)
+    if (hipMemcpyFromSymbol(out20, HIP_SYMBOL(g_drain_prof), sizeof(unsigned long long) * 20) != hipSuccess)
     {
         return -1;
     }
-    unsigned long long zero[16] = {0};
+    unsigned long long zero[20] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_drain_prof), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }

@@ -34,11 +34,34 @@ def test_bench_line_has_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # fetches shared by a wave are billed once: no more node fetches than node visits
     assert 0 < r["node_fetches_per_ray"] <= r["nodes_per_ray"]
-    for key in ("hbm_traffic_frac", "l2_frac", "td_busy", "lane_util"):
+    for key in ("hbm_traffic_frac", "hbm_achievable_frac", "l2_frac", "td_busy", "lane_util", "level", "level_peak",
+                "frac_at_level", "billed"):
         assert key in r, key
+    # 54k triangles: the tree fits one XCD's L2, so the bytes that must move are billed, and those stay below the peak
+    assert r["level"] == "l2" and r["billed"] == "compulsory" and 0 < r["frac"] <= 1
+    assert j["metric"] == "Mrays/s (whole node), dragon_small 320x180"
+    assert j["rank_elapsed_ms"]["spread"] == 0 and j["reduce_ms"] is None  # one rank
     assert j["primary_mrays_s"] > 0 and j["incoherent_mrays_s"] > 0
     c = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     assert c["reference_lavapipe"] == "unavailable"
+
+
+def test_a_tree_that_fits_l1_never_shows_more_than_the_peak():
+    """The Cornell box (32 triangles, 3 nodes) lives in every CU's L1: billing 80
+    bytes per node visit would count bytes that never leave the CU against HBM
+    (the per-visit rate there exceeds 8 TB/s). The line bills the bytes that must
+    move and says which level holds the tree."""
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--scene", "cornell", "--width", "1024", "--height", "1024",
+         "--max-depth", "8", "--spp-per-step", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+        capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    r = j["roofline"]
+    assert r["level"] == "l1" and r["billed"] == "compulsory" and r["frac_at_level"] is None
+    assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["algorithmic_gbs"] > r["achieved"]  # the per-visit rate is still reported, beside the billed one
+    assert j["cpu_baseline"] is None and j["metric"].endswith("cornell 1024x1024")

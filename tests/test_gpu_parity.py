@@ -44,6 +44,49 @@ def test_device_math_bit_exact(ctx, oracle):
     assert np.array_equal(_bits(ctx.math_eval(4, tiny, np.full(16, 2.0, np.float32))), _bits(tiny / np.float32(2)))
 
 
+def test_zero_aperture_lens_sample_keeps_only_the_signs(ctx, oracle):
+    """With aperture_radius == 0 (the reference's default, src/camera.cpp:87) the lens
+    sample of shader.rgen:184 is multiplied by zero; the kernels then skip the square
+    root and the polynomials and derive the signs of the two zeros from the angle's
+    quadrant. Those signs must be the signs of the values sincos_ computes, for every
+    angle 2 pi u the RNG can produce: checked on random draws, on the quadrant
+    boundaries and their float neighbours, on 0 and on u = 1.0."""
+    rng = np.random.default_rng(11)
+    u = (rng.integers(0, 2 ** 32, 400000, dtype=np.uint64).astype(np.float32) * np.float32(2.0 ** -32)).astype(np.float32)
+    edges = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 0.125, 0.375, 0.625, 0.875], np.float32)
+    near = np.concatenate([np.nextafter(edges, np.float32(2)), np.nextafter(edges, np.float32(-1)), edges,
+                           np.arange(1, 4097, dtype=np.float32) * np.float32(2.0 ** -32)])
+    u = np.concatenate([u, near[(near >= 0) & (near <= 1)]]).astype(np.float32)
+    theta = (np.float32(6.28318530717958647692) * u).astype(np.float32)
+    s, c = ctx.math_eval(0, theta)
+    out = np.empty_like(theta), np.empty_like(theta)
+    R._check(R.lib().ptc_math_eval(ctx.handle, 7, theta.ctypes.data, theta.ctypes.data, out[0].ctypes.data,
+                                   out[1].ctypes.data, theta.size))
+    assert np.array_equal(np.signbit(out[0]), np.signbit(s))
+    assert np.array_equal(np.signbit(out[1]), np.signbit(c))
+    assert (out[0] == 0).all() and (out[1] == 0).all()
+    # and a render whose camera has zeros of both signs in its position and an aperture of -0: the film equals
+    # the oracle's, which evaluates the lens sample in full
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(ctx, sc)
+    orc = oracle.Scene(*sc.oracle_args())
+    w, h = 40, 24
+    for aperture, pos_x in ((0.0, -0.0), (-0.0, 0.0), (0.05, -0.0)):
+        cam = R.default_camera(w, h)
+        cam.position.x, cam.position.y = pos_x, -0.0
+        cam.aperture_radius = aperture
+        for integrator in (R.INTEGRATOR_MEGAKERNEL, R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM):
+            rr = R.RenderResources(ctx, w, h, dev)
+            rr.max_depth, rr.integrator = 5, integrator
+            rr.render(cam, frame=1, n_frames=3)
+            ref_acc, ref_img, _ = orc.render(oracle.make_push(cam.as_dict(), frame=1), w, h, n_frames=3, max_depth=5,
+                                             use_bvh=False)
+            assert np.array_equal(_bits(rr.read_accum()), _bits(ref_acc)), (aperture, integrator)
+            assert np.array_equal(rr.read_rgba8(), ref_img)
+            rr.close()
+    dev.close()
+
+
 def _small_knot():
     return scenes.knot_mesh(nu=96, nv=24)
 

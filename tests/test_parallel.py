@@ -88,3 +88,28 @@ def test_strong_scaling_split_covers_the_step_once():
         counts = parallel.split_spp(total, world)
         frames = sorted(r + j * world for r in range(world) for j in range(counts[r]))
         assert frames == list(range(total))
+
+
+def test_bench_rank_code_path_without_a_gpu():
+    """bench.py --gpus 2 --dry-ranks: the launcher starts two ranks, which
+    rendezvous (gloo), work out their shares of every step with the function
+    the real run uses, reduce a stand-in film and exchange their timings; rank 0
+    alone prints one line. The union of the ranks' frames is the single-GPU
+    schedule, each frame once, for a step that does not divide evenly."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks", "--total-spp", "5",
+                          "--steps", "3"], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                         env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["step_total"] == 5
+    assert j["every_frame_rendered_once"] and j["frames_total"] == 15
+    assert "cpu_baseline" in j and j["cpu_baseline"] is None  # reported by the single-GPU run only, and said so
+    frames = {r["rank"]: r["frames"] for r in j["ranks"]}
+    assert frames[0] == [0, 2, 4, 5, 7, 9, 10, 12, 14] and frames[1] == [1, 3, 6, 8, 11, 13]
+    assert [r["spp_per_step"] for r in j["ranks"]] == [3, 2]
+    # weak scaling: every rank renders --spp-per-step dispatches per step
+    from bench import rank_frames
+    assert rank_frames(2, 8, 1, 4, 2) == (17, 4, 2)

@@ -3,9 +3,9 @@
 headline configuration once with the reference camera and once with the camera
 turned away from the scene (every camera ray misses), and prints the device
 time per phase of a 64-spp step."""
-import sys, torch
+import os, sys, torch
 torch.cuda.init()
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from path_tracer_amd import renderer as R, scenes
 ctx = R.create_context(0)
