@@ -24,8 +24,12 @@ def _scenes():
                     scenes.procedural_sky(32, 16))
     empty_mesh = R.Mesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
     with_empty = R.Scene([empty_mesh, knot], [R.Instance(R.IDENTITY, 0, 0), R.Instance(rot, 1, 2)], None)
+    # seven instances nested in one another: a ray through the middle meets all seven boxes, more than the
+    # per-ray list of nearest instances holds, and one through the rim meets a few (both walks in one wave)
+    nested = R.Scene([knot], [R.Instance((R.IDENTITY * np.float32(0.3 + 0.1 * i)).astype(np.float32), 0, i % 4)
+                              for i in range(7)], scenes.procedural_sky(32, 16))
     return {"ref4": scenes.ref4_scene(knot, scenes.procedural_sky(32, 16)), "multi": multi, "cornell": box,
-            "with_empty_mesh": with_empty}
+            "with_empty_mesh": with_empty, "nested7": nested}
 
 
 @pytest.fixture(scope="module", params=sorted(_scenes()))

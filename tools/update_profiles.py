@@ -33,7 +33,7 @@ a = ap.parse_args()
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
-stats = glob.glob(os.path.join(a.src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+stats = max(glob.glob(os.path.join(a.src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(dst, f"{a.tag}_{a.label}_kernel_stats.csv"))
 summary = json.load(open(os.path.join(a.src, "summary.json")))
 summary_name = f"{a.tag}_{a.label}_pmc_summary.json"
