@@ -177,3 +177,49 @@ def test_static_entry_point_allocates_no_device_memory(ctx):
     rr.close()
     dev.close()
     own.close()
+
+
+@pytest.mark.parametrize("integrator", [R.INTEGRATOR_WAVEFRONT, R.INTEGRATOR_STREAM, R.INTEGRATOR_MEGAKERNEL],
+                         ids=["wavefront", "stream", "megakernel"])
+def test_static_entry_point_is_captured_into_a_hip_graph(integrator):
+    """The callers the entry point exists for: code under HIP graph capture, where
+    an allocation, an event query or a synchronisation fails the capture. The
+    call is recorded on a capturing stream (nothing runs), the film is wiped,
+    and two replays of the graph each leave the film ptc_render leaves."""
+    torch = pytest.importorskip("torch")
+    ctx = R.create_context(0)
+    sc = scenes.cornell_box(tall_kind=1, short_kind=3)
+    dev = R.DeviceScene(ctx, sc)
+    w, h = 96, 64
+    cam = R.default_camera(w, h)
+    ref = R.RenderResources(ctx, w, h, dev)
+    ref.integrator, ref.max_depth = integrator, 6
+    ref.render(cam, frame=3, n_frames=4)
+    want = ref.read_accum()
+    stream = torch.cuda.Stream(device="cuda:0")
+    ctx.set_stream(stream.cuda_stream)
+    rr = R.RenderResources(ctx, w, h, dev)
+    rr.integrator, rr.max_depth = integrator, 6
+    rr.render(cam, frame=3, n_frames=4, static=True)  # kernels loaded before the capture
+    R.reset_render(rr)
+    ptr = rr.accum_device_ptr()
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        rr.render(cam, frame=3, n_frames=4, static=True)
+
+    class Film:  # the accumulator as torch sees foreign device memory
+        __cuda_array_interface__ = dict(shape=(h, w, 4), typestr="<f4", data=(ptr, False), version=2)
+
+    film = torch.as_tensor(Film(), device="cuda:0")
+    for _ in range(2):
+        with torch.cuda.stream(stream):
+            film.zero_()
+        graph.replay()
+        stream.synchronize()
+        assert np.array_equal(film.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    del graph
+    rr.close()
+    ref.close()
+    dev.close()
+    ctx.close()

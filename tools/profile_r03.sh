@@ -20,4 +20,8 @@ one torus10m --scene torus10m --max-depth 8 --spp-per-step 128 &&
 one ref4 --scene ref4 --spp-per-step 128 &&
 one ref4_two_level --scene ref4 --spp-per-step 128 --two-level &&
 one c5_4k --scene c5 --width 3840 --height 2160 --spp-per-step 64 &&
-one cornell1024 --scene cornell --width 1024 --height 1024 --max-depth 8
+one cornell1024 --scene cornell --width 1024 --height 1024 --max-depth 8 &&
+one cornell512 --scene cornell --width 512 --height 512 --max-depth 8 --spp-per-step 16 &&
+one dragon4k --width 3840 --height 2160 --spp-per-step 64 &&
+one mega_dragon4k --width 3840 --height 2160 --spp-per-step 16 --integrator megakernel &&
+one mega_c5_4k --scene c5 --width 3840 --height 2160 --spp-per-step 16 --integrator megakernel
