@@ -134,6 +134,11 @@ def main():
     acc, img, st = orc.render(O.make_push(cam.as_dict(), frame=3), 32, 32, n_frames=4, max_depth=8, use_bvh=False)
     np.savez_compressed(os.path.join(HERE, "cornell_32x32_4spp.npz"), accum_bits=acc.view(np.uint32), rgba8=img,
                         rays=np.uint64(st.rays))
+    # the same dispatches in the bounce-count debug view (shader.rgen:195-199, the branch under "#else")
+    accd, imgd, std = orc.render(O.make_push(cam.as_dict(), frame=3), 32, 32, n_frames=4, max_depth=8, use_bvh=False,
+                                 debug_view=1)
+    np.savez_compressed(os.path.join(HERE, "cornell_debug_view_32x32_4spp.npz"), accum_bits=accd.view(np.uint32),
+                        rgba8=imgd, rays=np.uint64(std.rays))
     sc2 = scenes.ref4_scene(scenes.knot_mesh(nu=48, nv=12), scenes.procedural_sky(32, 16))
     orc2 = O.Scene(*sc2.oracle_args())
     acc2, img2, st2 = orc2.render(O.make_push(cam.as_dict(), frame=0, samples_per_frame=2), 32, 32, n_frames=2,

@@ -22,12 +22,12 @@ def _unhex(words):
     return np.array([int(w, 16) for w in words], dtype=np.uint32)
 
 
-def _check_film(ctx, sc, fixture, frame, spf, n_frames, max_depth):
+def _check_film(ctx, sc, fixture, frame, spf, n_frames, max_depth, debug_view=0):
     gold = np.load(os.path.join(GOLDEN, fixture))
     dev = R.DeviceScene(ctx, sc)
     cam = R.default_camera(32, 32)
     rr = R.RenderResources(ctx, 32, 32, dev)
-    rr.max_depth = max_depth
+    rr.max_depth, rr.debug_view = max_depth, debug_view
     for integrator in ALL:
         rr.integrator = integrator
         R.reset_render(rr)
@@ -43,6 +43,11 @@ def _check_film(ctx, sc, fixture, frame, spf, n_frames, max_depth):
 def test_cornell_film_equals_the_committed_bits(ctx):
     _check_film(ctx, scenes.cornell_box(tall_kind=1, short_kind=3), "cornell_32x32_4spp.npz",
                 frame=3, spf=1, n_frames=4, max_depth=8)
+
+
+def test_cornell_debug_view_equals_the_committed_bits(ctx):
+    _check_film(ctx, scenes.cornell_box(tall_kind=1, short_kind=3), "cornell_debug_view_32x32_4spp.npz",
+                frame=3, spf=1, n_frames=4, max_depth=8, debug_view=1)
 
 
 def test_ref4_film_equals_the_committed_bits(ctx):

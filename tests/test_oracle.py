@@ -246,6 +246,11 @@ def test_render_golden_images(oracle):
                                   use_bvh=use_bvh)
         assert np.array_equal(acc.view(np.uint32), g["accum_bits"]) and np.array_equal(img, g["rgba8"])
         assert st.rays == int(g["rays"])
+    # the same dispatches in the bounce-count debug view: another film, the same rays
+    gd = np.load(os.path.join(GOLD, "cornell_debug_view_32x32_4spp.npz"))
+    acc, img, st = orc.render(oracle.make_push(cam.as_dict(), frame=3), 32, 32, n_frames=4, max_depth=8, debug_view=1)
+    assert np.array_equal(acc.view(np.uint32), gd["accum_bits"]) and np.array_equal(img, gd["rgba8"])
+    assert st.rays == int(gd["rays"]) == int(g["rays"])
     g = np.load(os.path.join(GOLD, "ref4_32x32_4spp.npz"))
     sc = scenes.ref4_scene(scenes.knot_mesh(nu=48, nv=12), scenes.procedural_sky(32, 16))
     orc = oracle.Scene(*sc.oracle_args())
