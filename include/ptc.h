@@ -302,7 +302,8 @@ int ptc_film_set_sample_count(ptc_film *film, uint32_t sample_count);
 int ptc_film_read_accum(ptc_film *film, float *rgba_out);    /* 4*w*h floats */
 int ptc_film_read_rgba8(ptc_film *film, uint8_t *rgba_out);  /* 4*w*h bytes */
 /* Device address of the RGBA32F accumulator. Launches the film's recorded
- * dispatches first (asynchronously, on the context's stream). */
+ * dispatches first (asynchronously, on the context's stream); NULL, with the
+ * reason in ptc_last_error(), if that launch fails. */
 void *ptc_film_accum_device_ptr(ptc_film *film);
 /* Tone-map the accumulator into the RGBA8 target again (after an external
  * reduction wrote the accumulator). sum_mode: divide rgb by alpha first. */

@@ -935,11 +935,11 @@ void *ptc_film_accum_device_ptr(ptc_film *film)
     }
     // like the read-backs: what the pointer shows includes every recorded dispatch
     // (launched on the context's stream; work the caller enqueues there afterwards
-    // is ordered behind it). An error of that launch is reported by the next call
-    // that flushes.
-    if (use_device(film->ctx) == PTC_OK)
+    // is ordered behind it). If that launch fails there is no pointer to a film
+    // worth reading: NULL, with the reason in ptc_last_error().
+    if (use_device(film->ctx) != PTC_OK || flush_film(film) != PTC_OK)
     {
-        (void)flush_film(film);
+        return nullptr;
     }
     return film->d_accum;
 }

@@ -301,9 +301,10 @@ k_wf_trace(DScene S, float tmax, WfState q, float4 *__restrict__ hit, uint2 *__r
 {
     __shared__ uint2 s_stack[kLdsStack * kBlock];
     const uint32_t n = *count;
-    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock)
+    // (64-bit loop counters in the grid-stride loops of this file: a queue may hold close to 2^32 paths)
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (uint64_t)gridDim.x * kBlock)
     {
-        const uint32_t i = order != nullptr ? order[j] : j; // the j-th ray traced is the one of slot i
+        const uint32_t i = order != nullptr ? order[j] : (uint32_t)j; // the j-th ray traced is the one of slot i
         const float4 a = q.a[i], b = q.b[i];
         const vec3 o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
         const Hit h = S.inst_box != nullptr
@@ -327,13 +328,14 @@ k_wf_shade(DScene S, WfBuffers B, uint32_t bounce, uint32_t max_depth, int src, 
     const WfState qi = B.q[src], qo = B.q[src ^ 1];
     const uint32_t n = B.counts[bounce];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t n_round = (n + kShadeBlock - 1u) / kShadeBlock * kShadeBlock; // whole blocks enter: every thread meets the barriers
-    for (uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x; i < n_round; i += gridDim.x * kShadeBlock)
+    const uint64_t n_round = ((uint64_t)n + kShadeBlock - 1u) / kShadeBlock * kShadeBlock; // whole blocks enter: every thread meets the barriers
+    for (uint64_t i64 = (uint64_t)blockIdx.x * kShadeBlock + threadIdx.x; i64 < n_round; i64 += (uint64_t)gridDim.x * kShadeBlock)
     {
+        const uint32_t i = (uint32_t)i64; // (only used when i64 < n)
         bool alive = false;
         PathState ps;
         uint32_t pid = 0;
-        if (i < n)
+        if (i64 < n)
         {
             pid = load_state(qi, i, ps);
             const float4 hr = B.hit[i];
@@ -441,9 +443,11 @@ __global__ void __launch_bounds__(kBlock)
 k_regroup_keys(DScene S, WfState q, uint32_t n_slots, uint32_t seg_cap, const uint32_t *__restrict__ fill,
                const uint32_t *__restrict__ count, uint32_t *__restrict__ keys, uint32_t *__restrict__ bins)
 {
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ((n_slots + 63u) & ~63u); i += gridDim.x * kBlock)
+    for (uint64_t i64 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i64 < (((uint64_t)n_slots + 63u) & ~(uint64_t)63u);
+         i64 += (uint64_t)gridDim.x * kBlock)
     {
-        const bool valid = i < n_slots && slot_filled(i, seg_cap, fill, count);
+        const uint32_t i = (uint32_t)i64;
+        const bool valid = i64 < n_slots && slot_filled(i, seg_cap, fill, count);
         uint32_t key = kRegroupBins; // (no key)
         if (valid)
         {
@@ -513,9 +517,11 @@ __global__ void __launch_bounds__(kBlock)
 k_regroup_scatter(uint32_t n_slots, uint32_t seg_cap, const uint32_t *__restrict__ fill, const uint32_t *__restrict__ count,
                   const uint32_t *__restrict__ keys, uint32_t *__restrict__ bins, uint32_t *__restrict__ order)
 {
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ((n_slots + 63u) & ~63u); i += gridDim.x * kBlock)
+    for (uint64_t i64 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i64 < (((uint64_t)n_slots + 63u) & ~(uint64_t)63u);
+         i64 += (uint64_t)gridDim.x * kBlock)
     {
-        const bool valid = i < n_slots && slot_filled(i, seg_cap, fill, count);
+        const uint32_t i = (uint32_t)i64;
+        const bool valid = i64 < n_slots && slot_filled(i, seg_cap, fill, count);
         const uint32_t key = valid ? keys[i] : kRegroupBins;
         // the lanes of a wave that share a key take consecutive places, in lane
         // order: neighbouring slots stay neighbours, so the gather through order[]

@@ -100,7 +100,7 @@ int main(int argc, char **argv)
         std::uint32_t width = 640, height = 480, spp = 64, spf = 1, depth = 32; // src/application.cpp:206-207
         std::uint32_t preview_every = 0, batch = 64;
         int device = 0;
-        bool megakernel = false, two_level = false;
+        bool megakernel = false, two_level = false, bounce_view = false;
         for (int i = 1; i < argc; ++i)
         {
             const std::string a = argv[i];
@@ -121,12 +121,13 @@ int main(int argc, char **argv)
             else if (a == "--device") device = std::atoi(next());
             else if (a == "--megakernel") megakernel = true;
             else if (a == "--two-level") two_level = true;
+            else if (a == "--bounce-view") bounce_view = true;
             else if (a == "--preview-every") preview_every = std::strtoul(next(), nullptr, 10);
             else if (a == "--batch") batch = std::max(1ul, std::strtoul(next(), nullptr, 10));
             else if (a[0] == '-')
             {
                 std::cerr << "Usage: " << argv[0] << " [<file.obj|.ply>] [--width W] [--height H] [--spp N] [--spf N] "
-                          << "[--depth D] [--megakernel] [--two-level] [--preview-every N] [--batch N] [--env sky.hdr] [--out image.png] [--device N]\n";
+                          << "[--depth D] [--megakernel] [--two-level] [--bounce-view] [--preview-every N] [--batch N] [--env sky.hdr] [--out image.png] [--device N]\n";
                 return EXIT_FAILURE;
             }
             else file = argv[i];
@@ -162,6 +163,7 @@ int main(int argc, char **argv)
         rr.samples_per_frame = spf;
         rr.max_depth = depth;
         rr.integrator = megakernel ? PTC_INTEGRATOR_MEGAKERNEL : PTC_INTEGRATOR_AUTO;
+        rr.debug_view = bounce_view ? 1u : 0u; // the view under "#else" at src/shaders/shader.rgen:195-199
 
         // camera of open_scene(), src/application.cpp:209-222
         const float vertical_fov = 45.0f / 180.0f * 3.14159265358979323846f;

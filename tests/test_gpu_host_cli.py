@@ -76,6 +76,16 @@ def test_obj_file_as_the_reference_scene(tmp_path, ctx):
     assert np.array_equal(rr.read_rgba8(), img2)
     rr.close()
     assert np.mean(img2 != img) < 0.01  # the two hit definitions differ in rounding only
+    # --bounce-view: the reference's debug view (shader.rgen:195-199), through the C++ mirror's debug_view
+    png3 = str(tmp_path / "knot3.png")
+    run_cli(str(obj), "--width", "80", "--height", "60", "--spp", "4", "--bounce-view", "--out", png3)
+    rr = R.create_render_resources(ctx, 80, 60, scenes.ref4_scene(R.import_meshes(str(obj))[0]))
+    rr.debug_view = 1
+    for frame in range(4):
+        rr.render(cam, frame=frame)
+    img3 = np.asarray(Image.open(png3))
+    assert np.array_equal(rr.read_rgba8(), img3) and not np.array_equal(img3, img)
+    rr.close()
 
 
 def test_env_map_from_hdr_file(tmp_path, ctx):
