@@ -283,13 +283,38 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     n_dev = torch.cuda.device_count()  # counting does not initialise the GPU
-    if n_dev < world:
+    # Rehearsal of the multi-rank path on a machine with fewer GPUs than ranks (a test hook, PTC_BENCH_REHEARSE=1):
+    # the ranks share the GPUs there are, rendezvous over gloo and take their collectives through host memory.
+    # Every line of the rank logic runs; the timings mean nothing.
+    rehearse = os.environ.get("PTC_BENCH_REHEARSE") == "1" and world > 1
+    if n_dev < world and not rehearse:
         raise SystemExit(f"bench.py: --gpus {world} needs {world} GPUs, this machine has {n_dev}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    local_rank = local_rank % n_dev if rehearse else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def reduce_to_rank0(tensor):
+        if rehearse:
+            host = tensor.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                tensor.copy_(host)
+        else:
+            dist.reduce(tensor, dst=0, op=dist.ReduceOp.SUM)
+
+    def all_reduce(tensor, op):
+        if rehearse:
+            host = tensor.cpu()
+            dist.all_reduce(host, op=op)
+            tensor.copy_(host)
+        else:
+            dist.all_reduce(tensor, op=op)
 
     from path_tracer_amd import parallel
     from path_tracer_amd import renderer as R
@@ -359,7 +384,7 @@ def main():
         step(k)
     if world > 1 and args.warmup > 0:
         # the collective's own warm-up (channel set-up for a buffer of this size), on a scratch tensor
-        dist.reduce(torch.zeros_like(accum), dst=0, op=dist.ReduceOp.SUM)
+        reduce_to_rank0(torch.zeros_like(accum))
     R.reset_render(rr)
     ctx.reset_stats()
     ctx.render_times()
@@ -374,7 +399,7 @@ def main():
     if world > 1:
         # the one collective of the run: per-rank sums -> rank 0 (timed on its own as well)
         t_red = time.perf_counter()
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        reduce_to_rank0(accum)
         torch.cuda.synchronize()
         reduce_ms = (time.perf_counter() - t_red) * 1e3
     sync_all()
@@ -389,9 +414,9 @@ def main():
     own = torch.tensor([t_steps, -t_steps], dtype=torch.float64, device=f"cuda:{local_rank}")
     if world > 1:
         tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dist.all_reduce(own, op=dist.ReduceOp.MAX)
+        all_reduce(tmax, dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.SUM)
+        all_reduce(own, dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
     total_rays, total_paths = float(t[1]), float(t[2])
     rank_elapsed_max_ms, rank_elapsed_min_ms = float(own[0]) * 1e3, -float(own[1]) * 1e3
@@ -482,7 +507,8 @@ def main():
                                    f"max depth {args.max_depth}, {args.integrator}"
                                    f"{', two-level scene' if args.two_level else ''}"
                                    f"{', queue regrouped by ray origin and octant' if args.regroup else ''}, spp sharded "
-                                   f"over {world} GPU(s), RCCL sum at the end",
+                                   f"over {world} GPU(s), RCCL sum at the end"
+                                   f"{' (REHEARSAL: ranks share a GPU, gloo through host memory; timings mean nothing)' if rehearse else ''}",
                        "triangles": info.n_triangles, "bvh_nodes": info.n_nodes,
                        "bvh_build_ms": round(info.build_ms, 2), "bvh_sah_cost": round(info.sah_cost, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

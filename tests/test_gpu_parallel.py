@@ -134,3 +134,37 @@ def test_bench_strong_scaling_line_on_one_gpu():
     j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert j["scaling"] == "strong" and j["n_gpus"] == 1
     assert abs(j["ms_per_spp"] * 12 - j["ms_per_step"] * 2) < 1e-2 * j["ms_per_step"] + 1e-3
+
+
+def test_bench_multi_rank_path_rehearsed_on_one_gpu():
+    """Every line of bench.py's rank logic with two ranks (launcher, rendezvous,
+    shares of a step, warm-up and final reduce onto rank 0, max / sum / spread
+    exchanges, rank 0 alone printing), on the one GPU a test box has: with
+    PTC_BENCH_REHEARSE=1 the ranks share the device and take their collectives
+    through gloo and host memory. The film the two ranks sum is the one a single
+    rank renders of the same schedule, up to fp32 summation order."""
+    import json
+    from PIL import Image
+    import numpy as np
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        lines, images = [], []
+        for gpus in (2, 1):
+            png = os.path.join(d, f"ranks{gpus}.png")
+            out = subprocess.run(
+                [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--scene", "dragon_small", "--width", "160",
+                 "--height", "90", "--total-spp", "6", "--steps", "2", "--warmup", "1", "--save-png", png],
+                capture_output=True, text=True, timeout=600, cwd=ROOT,
+                env=dict(os.environ, PTC_BENCH_REHEARSE="1", OMP_NUM_THREADS="4"))
+            assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+            found = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+            assert len(found) == 1
+            lines.append(json.loads(found[0]))
+            images.append(np.asarray(Image.open(png)).astype(np.int32))
+    two, one = lines
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["cpu_baseline"] is None
+    assert two["reduce_ms"] is not None and two["rank_elapsed_ms"]["spread"] >= 0
+    assert "REHEARSAL" in two["config"]["workload"] and "REHEARSAL" not in one["config"]["workload"]
+    # the same 12 dispatches either way: the same rays, and pictures that differ by summation order at most
+    assert abs(two["rays_per_path"] - one["rays_per_path"]) < 1e-9
+    assert np.abs(images[0] - images[1]).max() <= 1
