@@ -94,6 +94,8 @@ def parse_args():
     ap.add_argument("--save-png", default="")
     ap.add_argument("--wavefront-bounces", type=int, default=0)
     ap.add_argument("--search-radius", type=int, default=0)
+    ap.add_argument("--optimize-rounds", type=int, default=0,
+                    help="reinsertion rounds of the tree builder (0 = the library's default, -1 = none)")
     ap.add_argument("--two-level", action="store_true",
                     help="one tree per mesh + instance list instead of one tree over all instanced triangles")
     ap.add_argument("--regroup", action="store_true",
@@ -327,7 +329,8 @@ def main():
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     torch.cuda.synchronize()
     rr = R.create_render_resources(ctx, W, H, scene, accum_dev=accum.data_ptr(),
-                                   search_radius=args.search_radius, two_level=args.two_level)
+                                   search_radius=args.search_radius, two_level=args.two_level,
+                                   optimize_rounds=R.OPTIMIZE_NONE if args.optimize_rounds < 0 else args.optimize_rounds)
     rr.max_depth = args.max_depth
     rr.accumulate = R.ACCUM_SUM
     rr.wavefront_bounces = args.wavefront_bounces
@@ -510,7 +513,8 @@ def main():
                                    f"over {world} GPU(s), RCCL sum at the end"
                                    f"{' (REHEARSAL: ranks share a GPU, gloo through host memory; timings mean nothing)' if rehearse else ''}",
                        "triangles": info.n_triangles, "bvh_nodes": info.n_nodes,
-                       "bvh_build_ms": round(info.build_ms, 2), "bvh_sah_cost": round(info.sah_cost, 2)},
+                       "bvh_build_ms": round(info.build_ms, 2), "bvh_sah_cost": round(info.sah_cost, 2),
+                       "bvh_optimize_rounds": "default (8)" if args.optimize_rounds == 0 else args.optimize_rounds},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          # which bytes `achieved` bills: per-visit ("algorithmic": 80 B per node visit, 48 B per

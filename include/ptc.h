@@ -127,8 +127,18 @@ typedef struct ptc_build_options
      * 0 selects the default of 0.45 (a node visit fetches 80 bytes and tests
      * eight boxes, a triangle test fetches 48 bytes). */
     float tri_cost;
-    uint32_t reserved[4];
+    /* Rounds of subtree reinsertion run on the binary tree before it is cut
+     * into wide nodes: every round, every subtree looks for the place in the
+     * tree where it would add the least surface area, and the moves that do
+     * not touch each other are carried out. 0 selects the default of 8 rounds
+     * (871k triangles: 10 ms on top of a 3.6 ms build, 7 % fewer node visits
+     * per incoherent ray); PTC_OPTIMIZE_NONE skips the step; a round that moves
+     * nothing ends it early. The driver-side build this stands in for is asked
+     * to prefer trace speed over build time (src/renderer.cpp:1080, :1212). */
+    uint32_t optimize_rounds;
+    uint32_t reserved[3];
 } ptc_build_options;
+#define PTC_OPTIMIZE_NONE 0xffffffffu
 
 typedef struct ptc_scene_info
 {

@@ -653,6 +653,7 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
         build_params.search_radius = opts->search_radius;
         build_params.collapse = opts->collapse;
         build_params.tri_cost = opts->tri_cost;
+        build_params.optimize_rounds = opts->optimize_rounds;
         if (opts->collapse > 1u || !(opts->tri_cost >= 0.0f) || opts->tri_cost > 64.0f)
         {
             set_error("ptc_scene_create: unknown collapse rule or triangle cost outside [0, 64]");
@@ -663,6 +664,11 @@ int ptc_scene_create(ptc_context *ctx, const ptc_mesh_desc *meshes, uint32_t n_m
     if (const char *env = getenv("PTC_TRI_COST")) // measurement aid: overrides the triangle cost of the collapse
     {
         build_params.tri_cost = (float)atof(env);
+    }
+    if (const char *env = getenv("PTC_OPT_ROUNDS")) // measurement aid: rounds of reinsertion on the binary tree
+    {
+        const int r = atoi(env);
+        build_params.optimize_rounds = r <= 0 ? kNoOptimize : (uint32_t)r;
     }
     if (opts && opts->two_level)
     {

@@ -504,13 +504,306 @@ k_ploc_tail(uint32_t n, uint32_t n_leaves, uint32_t next_node, int radius,
     }
 }
 
-// ---- 4./5. collapse to 8-wide nodes, quantise ---------------------------------
-
 __device__ __forceinline__ float half_area(float4 lo, float4 hi)
 {
     const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
     return dx * dy + dy * dz + dz * dx;
 }
+
+// ---- 3b. reinsertion -----------------------------------------------------------
+// The clustering only ever merges neighbours along the Morton curve, so a subtree
+// can end up far (in the tree) from the place where it would add the least
+// surface area. Every round, every node `in` looks for the node X next to which
+// its subtree would be better placed: taking `in` out removes its parent P (the
+// sibling S takes P's place) and shrinks the boxes above; putting it back beside
+// X adds a node over (X, in) and grows the boxes above X up to the first common
+// ancestor (the pivot), above which nothing changes. The search climbs from P
+// to the root and, per ancestor, walks the subtree on the other side with the
+// bound "no node below X can gain more than what is left after the growth X's
+// own box causes" (after Meister and Bittner, "Parallel Reinsertion for Bounding
+// Volume Hierarchy Optimization", 2018). Moves are settled in three steps. A
+// move claims, with an atomic maximum of (gain, node), the nodes whose links it
+// rewrites or follows: in, P, S and X (a link of an unclaimed node, the slot of
+// P's parent or of X's parent, is only ever rewritten by the move that holds
+// the node the slot points at). The moves that hold all four then mark X's
+// ancestors below the pivot, and a move whose `in` carries such a mark stands
+// back: going up from a moved P, the only way to come down again into a subtree
+// that was moved as well is through an `in` that is an ancestor of some X, and
+// such an `in` at or above that move's pivot has a subtree strictly larger than
+// the one it was reached from, so the moves that remain cannot close a cycle:
+// they are the same as carried out one after the other. Boxes and triangle
+// counts are refitted after every round.
+
+constexpr uint32_t kNoNode = 0xffffffffu;
+constexpr int kOptStack = 64;
+constexpr uint32_t kDefaultOptimizeRounds = 8u;
+
+__global__ void __launch_bounds__(kBlock)
+k_opt_parents(uint32_t n_leaves, uint32_t n_internal, const uint2 *__restrict__ node_lr,
+              uint32_t *__restrict__ parent)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_internal)
+    {
+        return;
+    }
+    const uint2 lr = node_lr[i];
+    parent[lr.x] = n_leaves + i;
+    parent[lr.y] = n_leaves + i;
+    if (i == n_internal - 1u)
+    {
+        parent[n_leaves + i] = kNoNode; // the root is the last node made
+    }
+}
+
+__device__ __forceinline__ unsigned long long opt_key(float gain, uint32_t in)
+{
+    // gains are positive floats, whose bits order as integers; ties go to the larger id
+    return ((unsigned long long)__float_as_uint(gain) << 32) | in;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_opt_find(uint32_t n_leaves, uint32_t n_nodes, const float4 *__restrict__ node_lo,
+           const float4 *__restrict__ node_hi, const uint2 *__restrict__ node_lr,
+           const uint32_t *__restrict__ parent, uint32_t *__restrict__ cand_x,
+           uint32_t *__restrict__ cand_pivot, float *__restrict__ cand_gain,
+           unsigned long long *__restrict__ lock, uint32_t *__restrict__ n_cand)
+{
+    const uint32_t in = blockIdx.x * kBlock + threadIdx.x;
+    if (in >= n_nodes)
+    {
+        return;
+    }
+    const uint32_t root = n_nodes - 1u;
+    cand_gain[in] = 0.0f;
+    if (in == root)
+    {
+        return;
+    }
+    const uint32_t P = parent[in];
+    if (P == root)
+    {
+        return; // (the root stays: its children are not moved)
+    }
+    const float4 ilo = node_lo[in], ihi = node_hi[in];
+    const uint2 plr = node_lr[P - n_leaves];
+    const uint32_t S = plr.x == in ? plr.y : plr.x;
+    // what taking `in` out has gained so far on the way up: P itself, then the
+    // shrinking of every ancestor passed
+    float D = half_area(node_lo[P], node_hi[P]);
+    float best_gain = 0.0f;
+    uint32_t best_x = kNoNode, best_pivot = kNoNode;
+    uint32_t st_node[kOptStack];
+    float st_ind[kOptStack];
+    auto search = [&](uint32_t start, uint32_t pivot) {
+        int sp = 1;
+        st_node[0] = start;
+        st_ind[0] = 0.0f;
+        while (sp > 0)
+        {
+            --sp;
+            const uint32_t X = st_node[sp];
+            const float ind = st_ind[sp]; // growth of X's ancestors below the pivot
+            const float4 xlo = node_lo[X], xhi = node_hi[X];
+            const float m = merged_half_area(xlo, xhi, ilo, ihi);
+            const float gain = D - ind - m;
+            if (gain > best_gain)
+            {
+                best_gain = gain;
+                best_x = X;
+                best_pivot = pivot;
+            }
+            if (X >= n_leaves)
+            {
+                const float ind_below = ind + (m - half_area(xlo, xhi));
+                // no box inside X's, merged with in's, is smaller than in's box
+                // stretched across the gap between the two
+                const float gx = fmax_(fmax_(xlo.x - ihi.x, ilo.x - xhi.x), 0.0f);
+                const float gy = fmax_(fmax_(xlo.y - ihi.y, ilo.y - xhi.y), 0.0f);
+                const float gz = fmax_(fmax_(xlo.z - ihi.z, ilo.z - xhi.z), 0.0f);
+                const float ex = (ihi.x - ilo.x) + gx, ey = (ihi.y - ilo.y) + gy, ez = (ihi.z - ilo.z) + gz;
+                const float m_below = ex * ey + ey * ez + ez * ex;
+                if (D - ind_below - m_below > best_gain && sp + 2 <= kOptStack)
+                {
+                    const uint2 lr = node_lr[X - n_leaves];
+                    st_node[sp] = lr.x;
+                    st_ind[sp] = ind_below;
+                    st_node[sp + 1] = lr.y;
+                    st_ind[sp + 1] = ind_below;
+                    sp += 2;
+                }
+            }
+        }
+    };
+    // below the sibling first (S itself gives back the tree as it is: gain 0)
+    search(S, P);
+    uint32_t child = P;
+    float4 plo = node_lo[S], phi = node_hi[S]; // box of the path node without `in`
+    for (;;)
+    {
+        const uint32_t A = parent[child];
+        const uint2 alr = node_lr[A - n_leaves];
+        const uint32_t C = alr.x == child ? alr.y : alr.x;
+        search(C, A);
+        if (A == root)
+        {
+            break;
+        }
+        const float4 clo = node_lo[C], chi = node_hi[C];
+        plo.x = fmin_(plo.x, clo.x);
+        plo.y = fmin_(plo.y, clo.y);
+        plo.z = fmin_(plo.z, clo.z);
+        phi.x = fmax_(phi.x, chi.x);
+        phi.y = fmax_(phi.y, chi.y);
+        phi.z = fmax_(phi.z, chi.z);
+        D += half_area(node_lo[A], node_hi[A]) - half_area(plo, phi);
+        child = A;
+    }
+    if (best_x == kNoNode || !(best_gain > 0.0f))
+    {
+        return;
+    }
+    if (n_cand != nullptr)
+    {
+        atomicAdd(n_cand, 1u); // (tracing only)
+    }
+    cand_gain[in] = best_gain;
+    cand_x[in] = best_x;
+    cand_pivot[in] = best_pivot;
+    const unsigned long long key = opt_key(best_gain, in);
+    atomicMax(&lock[in], key);
+    atomicMax(&lock[P], key);
+    atomicMax(&lock[S], key);
+    atomicMax(&lock[best_x], key);
+}
+
+// Whether the move of `in` holds all its claims; with them, P and S are in's
+// parent and sibling as the search saw them.
+__device__ __forceinline__ bool opt_holds(uint32_t in, uint32_t n_leaves, const uint2 *__restrict__ node_lr,
+                                          const uint32_t *__restrict__ parent, const uint32_t *__restrict__ cand_x,
+                                          const float *__restrict__ cand_gain,
+                                          const unsigned long long *__restrict__ lock, uint32_t &P, uint32_t &S)
+{
+    const float gain = cand_gain[in];
+    if (!(gain > 0.0f))
+    {
+        return false;
+    }
+    const unsigned long long key = opt_key(gain, in);
+    P = parent[in];
+    const uint2 plr = node_lr[P - n_leaves];
+    S = plr.x == in ? plr.y : plr.x;
+    return lock[in] == key && lock[P] == key && lock[S] == key && lock[cand_x[in]] == key;
+}
+
+// The moves that hold their claims mark the ancestors of X below the pivot.
+__global__ void __launch_bounds__(kBlock)
+k_opt_mark(uint32_t n_leaves, uint32_t n_nodes, const uint2 *__restrict__ node_lr,
+           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ cand_x,
+           const uint32_t *__restrict__ cand_pivot, const float *__restrict__ cand_gain,
+           const unsigned long long *__restrict__ lock, uint32_t *__restrict__ marked)
+{
+    const uint32_t in = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t P, S;
+    if (in >= n_nodes || !opt_holds(in, n_leaves, node_lr, parent, cand_x, cand_gain, lock, P, S))
+    {
+        return;
+    }
+    const uint32_t pivot = cand_pivot[in];
+    for (uint32_t x = parent[cand_x[in]]; x != pivot; x = parent[x])
+    {
+        marked[x] = 1u;
+    }
+}
+
+// Carries out the moves that hold their claims and whose `in` is not marked.
+__global__ void __launch_bounds__(kBlock)
+k_opt_apply(uint32_t n_leaves, uint32_t n_nodes, uint2 *__restrict__ node_lr, uint32_t *__restrict__ parent,
+            const uint32_t *__restrict__ cand_x, const float *__restrict__ cand_gain,
+            const unsigned long long *__restrict__ lock, const uint32_t *__restrict__ marked,
+            uint32_t *__restrict__ n_moved)
+{
+    const uint32_t in = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t P = 0u, S = 0u;
+    const bool go = in < n_nodes && opt_holds(in, n_leaves, node_lr, parent, cand_x, cand_gain, lock, P, S) &&
+                    marked[in] == 0u;
+    const unsigned long long moving = __ballot(go);
+    if (moving != 0ull && (threadIdx.x & 63u) == 0u)
+    {
+        atomicAdd(n_moved, (uint32_t)__builtin_popcountll(moving));
+    }
+    if (!go)
+    {
+        return;
+    }
+    const uint32_t X = cand_x[in], G = parent[P];
+    const uint32_t pX = parent[X];
+    // S takes P's place below G
+    uint32_t *g = reinterpret_cast<uint32_t *>(&node_lr[G - n_leaves]);
+    if (g[0] == P)
+    {
+        g[0] = S;
+    }
+    else
+    {
+        g[1] = S;
+    }
+    parent[S] = G;
+    // P goes between X and X's parent (which may be G or S: read again after the step above)
+    uint32_t *q = reinterpret_cast<uint32_t *>(&node_lr[pX - n_leaves]);
+    if (q[0] == X)
+    {
+        q[0] = P;
+    }
+    else
+    {
+        q[1] = P;
+    }
+    parent[P] = pX;
+    node_lr[P - n_leaves] = make_uint2(in, X);
+    parent[X] = P;
+}
+
+// Boxes and triangle counts of the internal nodes, bottom-up, one launch per
+// height: launch number `pass` (1, 2, ...) does the nodes whose children were
+// done by earlier launches and leaves its number in height[], so a node of
+// height h is done by launch h, from values that launches before it wrote.
+// (One launch in which threads climb from the leaves and meet at the nodes needs
+// a release and an acquire across the chip's eight L2s at every node: 3.3 ms
+// for 871k leaves, against 0.3 ms for some forty of these launches.)
+// The root is the last internal node: once its height is set, all are.
+__global__ void __launch_bounds__(kBlock)
+k_opt_refit_pass(uint32_t pass, uint32_t n_leaves, uint32_t n_internal, const uint2 *__restrict__ node_lr,
+                 float4 *__restrict__ node_lo, float4 *__restrict__ node_hi, uint32_t *__restrict__ height)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_internal || height[i] != 0u)
+    {
+        return;
+    }
+    const uint2 lr = node_lr[i];
+    const uint32_t hl = lr.x < n_leaves ? 0u : height[lr.x - n_leaves];
+    const uint32_t hr = lr.y < n_leaves ? 0u : height[lr.y - n_leaves];
+    if (!((lr.x < n_leaves || (hl != 0u && hl < pass)) && (lr.y < n_leaves || (hr != 0u && hr < pass))))
+    {
+        return;
+    }
+    const float4 alo = node_lo[lr.x], ahi = node_hi[lr.x], blo = node_lo[lr.y], bhi = node_hi[lr.y];
+    float4 lo, hi;
+    lo.x = fmin_(alo.x, blo.x);
+    lo.y = fmin_(alo.y, blo.y);
+    lo.z = fmin_(alo.z, blo.z);
+    hi.x = fmax_(ahi.x, bhi.x);
+    hi.y = fmax_(ahi.y, bhi.y);
+    hi.z = fmax_(ahi.z, bhi.z);
+    lo.w = __uint_as_float(__float_as_uint(alo.w) + __float_as_uint(blo.w));
+    hi.w = 0.0f;
+    node_lo[n_leaves + i] = lo;
+    node_hi[n_leaves + i] = hi;
+    height[i] = pass;
+}
+
+// ---- 4./5. collapse to 8-wide nodes, quantise ---------------------------------
 
 
 // Cost-optimal collapse. For a binary node n and a budget of i subtree roots
@@ -679,6 +972,28 @@ k_collapse_cost_tail(uint32_t first, uint32_t last, uint32_t n_leaves, float tri
             break;
         }
     }
+}
+
+// The same table for a tree whose node ids no longer say which nodes are below
+// which (after reinsertion): one launch per height, as the refit left it in
+// height[] (k_opt_refit_pass).
+__global__ void __launch_bounds__(kBlock)
+k_collapse_cost_height(uint32_t pass, uint32_t n_leaves, uint32_t n_internal, float tri_cost,
+                       const float4 *__restrict__ node_lo, const float4 *__restrict__ node_hi,
+                       const uint2 *__restrict__ node_lr, const uint32_t *__restrict__ height,
+                       CollapseCost *__restrict__ table)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_internal || height[i] != pass)
+    {
+        return;
+    }
+    const uint2 lr = node_lr[i];
+    const CollapseCost L = collapse_cost_of(lr.x, n_leaves, tri_cost, node_lo, node_hi, table);
+    const CollapseCost R = collapse_cost_of(lr.y, n_leaves, tri_cost, node_lo, node_hi, table);
+    CollapseCost out;
+    collapse_cost_node(n_leaves + i, n_leaves, tri_cost, node_lo, node_hi, node_lr, L, R, out);
+    table[i] = out;
 }
 
 // For every wide node of the current level: pick its (up to 8) children among
@@ -1130,8 +1445,8 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
     const float tri_cost = params.tri_cost > 0.0f ? params.tri_cost : kDefaultTriCost;
     const bool greedy = params.collapse == 1u;
     TempPool pool;
-    // about 390 bytes of scratch per triangle, plus the sort's and the scan's own
-    PTC_HIP_CHECK(pool.reserve((size_t)n * 512 + (1u << 20)));
+    // about 450 bytes of scratch per triangle, plus the sort's and the scan's own
+    PTC_HIP_CHECK(pool.reserve((size_t)n * 576 + (1u << 20)));
 
     // outputs
     const size_t node_cap = std::max<size_t>(n, 1);
@@ -1279,7 +1594,86 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
             next_node = h_tot[1];
         }
         const uint32_t binary_root = n == 1 ? 0u : next_node - 1u;
-        if (!greedy)
+        // reinsertion rounds on the binary tree (see 3b)
+        uint32_t opt_rounds = params.optimize_rounds == kNoOptimize
+                                  ? 0u
+                                  : (params.optimize_rounds ? params.optimize_rounds : kDefaultOptimizeRounds);
+        uint32_t *parent = nullptr, *height = nullptr;
+        uint32_t tree_height = 0u;
+        if (n < 4u || next_node != 2u * n - 1u)
+        {
+            opt_rounds = 0u;
+        }
+        if (opt_rounds > 0u)
+        {
+            const uint32_t n_bin = 2u * n - 1u, n_int = n - 1u;
+            uint32_t *cand_x, *cand_pivot, *counts, *marked;
+            float *cand_gain;
+            unsigned long long *lock;
+            PTC_HIP_CHECK(pool.alloc(&parent, n_bin));
+            PTC_HIP_CHECK(pool.alloc(&height, n));
+            PTC_HIP_CHECK(pool.alloc(&cand_x, n_bin));
+            PTC_HIP_CHECK(pool.alloc(&cand_pivot, n_bin));
+            PTC_HIP_CHECK(pool.alloc(&cand_gain, n_bin));
+            PTC_HIP_CHECK(pool.alloc(&lock, n_bin));
+            PTC_HIP_CHECK(pool.alloc(&counts, 2)); // moves, candidates
+            PTC_HIP_CHECK(pool.alloc(&marked, n_bin));
+            const bool trace = getenv("PTC_OPT_TRACE") != nullptr;
+            k_opt_parents<<<blocks_for(n_int), kBlock, 0, st>>>(n, n_int, node_lr, parent);
+            uint32_t passes = 24u; // launches of the refit before the host first looks
+            for (uint32_t round = 0; round < opt_rounds; ++round)
+            {
+                PTC_HIP_CHECK(hipMemsetAsync(lock, 0, (size_t)n_bin * 8, st));
+                PTC_HIP_CHECK(hipMemsetAsync(counts, 0, 8, st));
+                PTC_HIP_CHECK(hipMemsetAsync(marked, 0, (size_t)n_bin * 4, st));
+                PTC_HIP_CHECK(hipMemsetAsync(height, 0, (size_t)n * 4, st));
+                k_opt_find<<<blocks_for(n_bin), kBlock, 0, st>>>(n, n_bin, node_lo, node_hi, node_lr, parent, cand_x,
+                                                                 cand_pivot, cand_gain, lock, trace ? counts + 1 : nullptr);
+                k_opt_mark<<<blocks_for(n_bin), kBlock, 0, st>>>(n, n_bin, node_lr, parent, cand_x, cand_pivot, cand_gain,
+                                                                 lock, marked);
+                k_opt_apply<<<blocks_for(n_bin), kBlock, 0, st>>>(n, n_bin, node_lr, parent, cand_x, cand_gain, lock,
+                                                                  marked, counts);
+                // counts: moves, candidates, the root's height (0 until the refit has reached it)
+                uint32_t h_counts[3] = {0u, 0u, 0u};
+                for (uint32_t pass = 0u; h_counts[2] == 0u;)
+                {
+                    for (uint32_t k = 0; k < passes; ++k)
+                    {
+                        k_opt_refit_pass<<<blocks_for(n_int), kBlock, 0, st>>>(++pass, n, n_int, node_lr, node_lo, node_hi,
+                                                                               height);
+                    }
+                    PTC_HIP_CHECK(hipMemcpyAsync(h_counts, counts, 8, hipMemcpyDeviceToHost, st));
+                    PTC_HIP_CHECK(hipMemcpyAsync(h_counts + 2, height + (n_int - 1u), 4, hipMemcpyDeviceToHost, st));
+                    PTC_HIP_CHECK(hipStreamSynchronize(st));
+                    if (h_counts[2] == 0u && pass > 2u * n)
+                    {
+                        set_error("BVH build: refit after reinsertion does not finish (links of the tree are broken)");
+                        return PTC_E_DEVICE;
+                    }
+                    passes = 8u;
+                }
+                tree_height = h_counts[2];
+                passes = tree_height + 2u; // the next round's tree is about as high
+                if (trace)
+                {
+                    fprintf(stderr, "ptc: reinsertion round %u moved %u of %u candidates (%u nodes, height %u)\n", round,
+                            h_counts[0], h_counts[1], n_bin, tree_height);
+                }
+                if (h_counts[0] == 0u)
+                {
+                    break;
+                }
+            }
+        }
+        if (!greedy && opt_rounds > 0u)
+        {
+            for (uint32_t pass = 1u; pass <= tree_height; ++pass)
+            {
+                k_collapse_cost_height<<<blocks_for(n - 1u), kBlock, 0, st>>>(pass, n, n - 1u, tri_cost, node_lo, node_hi,
+                                                                            node_lr, height, cost_table);
+            }
+        }
+        else if (!greedy)
         {
             for (const auto &r : round_nodes)
             {

@@ -165,7 +165,11 @@ struct BuildParams
     uint32_t search_radius = 0;
     uint32_t collapse = 0; // 0: cost-optimal choice of the wide nodes; 1: greedy by area
     float tri_cost = 0.0f; // cost of a triangle test relative to a node visit
+    // rounds of subtree reinsertion run on the binary tree before it is cut into
+    // wide nodes (0 = default; kNoOptimize = none)
+    uint32_t optimize_rounds = 0;
 };
+constexpr uint32_t kNoOptimize = 0xffffffffu;
 
 // BVH build on the device (ptc_bvh_build.hip). Fills scene->d_nodes, d_tris,
 // d.nodes, d.tris and the BVH fields of scene->info.

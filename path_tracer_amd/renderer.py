@@ -89,9 +89,12 @@ class ImportOptions(C.Structure):
 IMPORT_NO_NORMALIZE, IMPORT_NO_JOIN, IMPORT_EXACT_MATCH, IMPORT_FAN = 1, 2, 4, 8
 
 
+OPTIMIZE_NONE = 0xffffffff
+
+
 class BuildOptions(C.Structure):
     _fields_ = [("search_radius", C.c_uint32), ("two_level", C.c_uint32), ("collapse", C.c_uint32),
-                ("tri_cost", C.c_float), ("reserved", C.c_uint32 * 4)]
+                ("tri_cost", C.c_float), ("optimize_rounds", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class SceneInfo(C.Structure):
@@ -400,7 +403,8 @@ def create_context(device: int = 0) -> RenderContext:
 
 class DeviceScene:
     def __init__(self, ctx: RenderContext, scene: Scene, search_radius: int = 0, two_level: bool = False,
-                 collapse: int = 0, tri_cost: float = 0.0):
+                 collapse: int = 0, tri_cost: float = 0.0, optimize_rounds: int = 0):
+        # optimize_rounds: 0 = the library's default, OPTIMIZE_NONE = no reinsertion rounds
         self.ctx = ctx
         self.two_level = two_level
         keep = []
@@ -430,6 +434,7 @@ class DeviceScene:
         opts.two_level = int(two_level)
         opts.collapse = collapse
         opts.tri_cost = tri_cost
+        opts.optimize_rounds = optimize_rounds
         h = C.c_void_p()
         _check(lib().ptc_scene_create(ctx.handle, md, len(scene.meshes), idesc,
                                       len(scene.instances), C.byref(env) if env else None,
@@ -487,10 +492,12 @@ class RenderResources:
     + render target + the three sample counters the UI edits."""
 
     def __init__(self, ctx: RenderContext, width: int, height: int, scene,
-                 accum_dev: int = 0, rgba8_dev: int = 0, search_radius: int = 0, two_level: bool = False):
+                 accum_dev: int = 0, rgba8_dev: int = 0, search_radius: int = 0, two_level: bool = False,
+                 optimize_rounds: int = 0):
         self.ctx = ctx
         self.width, self.height = width, height
-        self.scene = scene if isinstance(scene, DeviceScene) else DeviceScene(ctx, scene, search_radius, two_level)
+        self.scene = scene if isinstance(scene, DeviceScene) else DeviceScene(ctx, scene, search_radius, two_level,
+                                                                                optimize_rounds=optimize_rounds)
         h = C.c_void_p()
         _check(lib().ptc_film_create(ctx.handle, width, height, C.c_void_p(accum_dev or None),
                                      C.c_void_p(rgba8_dev or None), C.byref(h)))

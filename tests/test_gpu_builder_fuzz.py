@@ -70,3 +70,51 @@ def test_builder_on_adversarial_distributions(ctx, oracle, n):
             for f in ("t", "u", "v"):
                 assert np.array_equal(hits[f][same].view(np.uint32), ref[f][same].view(np.uint32)), (name, n, two_level, f)
             dev.close()
+
+
+def test_reinsertion_rounds_keep_the_tree_valid_and_lower_its_cost(ctx, oracle):
+    """The builder's reinsertion step (subtrees moved to where they add the least
+    surface area, several rounds): whatever the number of rounds, every triangle
+    stays in the tree once, boxes contain their subtrees, rays hit what brute
+    force finds; the cost falls with the rounds; two builds give the same bytes."""
+    rng = np.random.default_rng(77)
+    shapes = dict(_shapes(rng, 20000))
+    cases = [("uniform", R.Scene([_soup(shapes["uniform"])], [R.Instance(R.IDENTITY, 0, 0)], None)),
+             ("huge among tiny", R.Scene([_soup(shapes["huge among tiny"])], [R.Instance(R.IDENTITY, 0, 1)], None)),
+             ("mesh in a box", scenes.dragon_in_cornell(nu=116, nv=59))]
+    for name, sc in cases:
+        orc = oracle.Scene(*sc.oracle_args())
+        world = orc.world_triangles()
+        rays = scenes.random_rays(20000, seed=5)
+        ref, _ = orc.intersect(rays, use_bvh=True)
+        hit = ref["id"] != oracle.NO_HIT
+        costs = {}
+        for rounds in (R.OPTIMIZE_NONE, 1, 0, 40):
+            dev = R.DeviceScene(ctx, sc, optimize_rounds=rounds)
+            nodes, tris = dev.read_bvh()
+            rc, _ = oracle.bvh8_validate(nodes, tris, world)
+            assert rc == 0, (name, rounds, rc)
+            hits = dev.trace(rays)
+            assert np.array_equal(hits["flat"], ref["id"]), (name, rounds)
+            for f in "tuv":
+                assert np.array_equal(hits[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)), (name, rounds, f)
+            costs[rounds] = dev.info.sah_cost
+            again = R.DeviceScene(ctx, sc, optimize_rounds=rounds)
+            nodes2, tris2 = again.read_bvh()
+            assert np.array_equal(nodes, nodes2) and np.array_equal(tris, tris2), (name, rounds)
+            again.close()
+            dev.close()
+        print(f"{name}: SAH cost without / 1 / 8 / 40 rounds: {costs[R.OPTIMIZE_NONE]:.2f} {costs[1]:.2f} {costs[0]:.2f} {costs[40]:.2f}")
+        assert costs[1] < costs[R.OPTIMIZE_NONE] and costs[0] < costs[1] and costs[40] <= costs[0] * 1.001, (name, costs)
+
+
+def test_two_level_trees_are_reinserted_too(ctx, oracle):
+    sc = scenes.ref4_scene(scenes.knot_mesh(nu=116, nv=59))
+    a = R.DeviceScene(ctx, sc, two_level=True, optimize_rounds=R.OPTIMIZE_NONE)
+    b = R.DeviceScene(ctx, sc, two_level=True)
+    assert b.info.sah_cost < a.info.sah_cost
+    rays = scenes.random_rays(20000, seed=6)
+    ref, _ = oracle.Scene(*sc.oracle_args(), two_level=True).intersect(rays, use_bvh=True)
+    assert np.array_equal(b.trace(rays)["flat"], ref["id"])
+    a.close()
+    b.close()

@@ -37,9 +37,9 @@ def test_dragon_bvh_valid_and_hits_match_oracle(dragon, oracle):
 
 
 def test_tree_quality_against_top_down_sah(dragon, ctx, oracle):
-    """SAH cost of the device's wide tree (bottom-up clustering) against the same
-    cost of the 8-wide collapse of the oracle's top-down binned-SAH tree: within
-    15 % on the dragon stand-in, the Cornell box and the dragon in the box."""
+    """SAH cost of the device's wide tree (bottom-up clustering, then reinsertion) against the same
+    cost of the 8-wide collapse of the oracle's top-down binned-SAH tree: no higher
+    on the dragon stand-in, the Cornell box and the dragon in the box."""
     sc, dev, orc = dragon
     pairs = [("dragon", dev.info.sah_cost, orc.wide_sah_cost()[0])]
     for name, other in (("cornell", scenes.cornell_box()), ("dragon in box", scenes.dragon_in_cornell(nu=232, nv=117))):
@@ -48,7 +48,8 @@ def test_tree_quality_against_top_down_sah(dragon, ctx, oracle):
         d.close()
     for name, device_cost, yardstick in pairs:
         print(f"{name}: device SAH {device_cost:.2f}, top-down binned SAH collapsed 8-wide {yardstick:.2f}")
-        assert device_cost <= 1.15 * yardstick, name
+        # (clustering alone: within 4 % above the yardstick; the reinsertion rounds, on by default, take it below)
+        assert device_cost <= yardstick, name
 
 
 def test_dragon_1080p_primary_ids_match_oracle(dragon, oracle):
