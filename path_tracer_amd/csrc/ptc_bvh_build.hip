@@ -538,9 +538,11 @@ constexpr uint32_t kNoNode = 0xffffffffu;
 constexpr int kOptStack = 64;
 constexpr uint32_t kDefaultOptimizeRounds = 8u;
 
+// up[id] = (parent, sibling) of every node, from the child links; the root's
+// parent is kNoNode. Rebuilt before every round, so the moves only rewrite
+// child links.
 __global__ void __launch_bounds__(kBlock)
-k_opt_parents(uint32_t n_leaves, uint32_t n_internal, const uint2 *__restrict__ node_lr,
-              uint32_t *__restrict__ parent)
+k_opt_links(uint32_t n_leaves, uint32_t n_internal, const uint2 *__restrict__ node_lr, uint2 *__restrict__ up)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_internal)
@@ -548,11 +550,11 @@ k_opt_parents(uint32_t n_leaves, uint32_t n_internal, const uint2 *__restrict__ 
         return;
     }
     const uint2 lr = node_lr[i];
-    parent[lr.x] = n_leaves + i;
-    parent[lr.y] = n_leaves + i;
+    up[lr.x] = make_uint2(n_leaves + i, lr.y);
+    up[lr.y] = make_uint2(n_leaves + i, lr.x);
     if (i == n_internal - 1u)
     {
-        parent[n_leaves + i] = kNoNode; // the root is the last node made
+        up[n_leaves + i] = make_uint2(kNoNode, kNoNode); // the root is the last node made
     }
 }
 
@@ -565,7 +567,7 @@ __device__ __forceinline__ unsigned long long opt_key(float gain, uint32_t in)
 __global__ void __launch_bounds__(kBlock)
 k_opt_find(uint32_t n_leaves, uint32_t n_nodes, const float4 *__restrict__ node_lo,
            const float4 *__restrict__ node_hi, const uint2 *__restrict__ node_lr,
-           const uint32_t *__restrict__ parent, uint32_t *__restrict__ cand_x,
+           const uint2 *__restrict__ up, uint32_t *__restrict__ cand_x,
            uint32_t *__restrict__ cand_pivot, float *__restrict__ cand_gain,
            unsigned long long *__restrict__ lock, uint32_t *__restrict__ n_cand)
 {
@@ -580,31 +582,41 @@ k_opt_find(uint32_t n_leaves, uint32_t n_nodes, const float4 *__restrict__ node_
     {
         return;
     }
-    const uint32_t P = parent[in];
+    const uint32_t P = up[in].x, S = up[in].y;
     if (P == root)
     {
         return; // (the root stays: its children are not moved)
     }
     const float4 ilo = node_lo[in], ihi = node_hi[in];
-    const uint2 plr = node_lr[P - n_leaves];
-    const uint32_t S = plr.x == in ? plr.y : plr.x;
+    // Two boxes go up the path with the search: the path node's own (the union
+    // of all below it, which is what the refit stored there) and the same
+    // without `in`. A level then reads the other child's box and nothing else.
+    float4 plo = node_lo[S], phi = node_hi[S];
+    float4 olo = plo, ohi = phi;
+    auto widen = [](float4 &lo, float4 &hi, float4 blo, float4 bhi) {
+        lo.x = fmin_(lo.x, blo.x);
+        lo.y = fmin_(lo.y, blo.y);
+        lo.z = fmin_(lo.z, blo.z);
+        hi.x = fmax_(hi.x, bhi.x);
+        hi.y = fmax_(hi.y, bhi.y);
+        hi.z = fmax_(hi.z, bhi.z);
+    };
+    widen(olo, ohi, ilo, ihi);
     // what taking `in` out has gained so far on the way up: P itself, then the
     // shrinking of every ancestor passed
-    float D = half_area(node_lo[P], node_hi[P]);
+    float D = half_area(olo, ohi);
     float best_gain = 0.0f;
     uint32_t best_x = kNoNode, best_pivot = kNoNode;
     uint32_t st_node[kOptStack];
     float st_ind[kOptStack];
-    auto search = [&](uint32_t start, uint32_t pivot) {
-        int sp = 1;
-        st_node[0] = start;
-        st_ind[0] = 0.0f;
-        while (sp > 0)
+    // candidates in the subtree of `start` (whose box the caller has at hand)
+    auto search = [&](uint32_t start, float4 slo, float4 shi, uint32_t pivot) {
+        int sp = 0;
+        uint32_t X = start;
+        float ind = 0.0f; // growth of X's ancestors below the pivot
+        float4 xlo = slo, xhi = shi;
+        for (;;)
         {
-            --sp;
-            const uint32_t X = st_node[sp];
-            const float ind = st_ind[sp]; // growth of X's ancestors below the pivot
-            const float4 xlo = node_lo[X], xhi = node_hi[X];
             const float m = merged_half_area(xlo, xhi, ilo, ihi);
             const float gain = D - ind - m;
             if (gain > best_gain)
@@ -633,31 +645,39 @@ k_opt_find(uint32_t n_leaves, uint32_t n_nodes, const float4 *__restrict__ node_
                     sp += 2;
                 }
             }
+            if (sp == 0)
+            {
+                break;
+            }
+            --sp;
+            X = st_node[sp];
+            ind = st_ind[sp];
+            xlo = node_lo[X];
+            xhi = node_hi[X];
         }
     };
     // below the sibling first (S itself gives back the tree as it is: gain 0)
-    search(S, P);
-    uint32_t child = P;
-    float4 plo = node_lo[S], phi = node_hi[S]; // box of the path node without `in`
+    search(S, plo, phi, P);
+    // (the links of the level above are requested before a level's subtree is
+    // searched: the climb is a chain of dependent loads, and this takes one of
+    // them off every level)
+    uint2 link = up[P];
     for (;;)
     {
-        const uint32_t A = parent[child];
-        const uint2 alr = node_lr[A - n_leaves];
-        const uint32_t C = alr.x == child ? alr.y : alr.x;
-        search(C, A);
+        const uint32_t A = link.x, C = link.y;
+        const float4 clo = node_lo[C], chi = node_hi[C];
+        if (A != root)
+        {
+            link = up[A];
+        }
+        search(C, clo, chi, A);
         if (A == root)
         {
             break;
         }
-        const float4 clo = node_lo[C], chi = node_hi[C];
-        plo.x = fmin_(plo.x, clo.x);
-        plo.y = fmin_(plo.y, clo.y);
-        plo.z = fmin_(plo.z, clo.z);
-        phi.x = fmax_(phi.x, chi.x);
-        phi.y = fmax_(phi.y, chi.y);
-        phi.z = fmax_(phi.z, chi.z);
-        D += half_area(node_lo[A], node_hi[A]) - half_area(plo, phi);
-        child = A;
+        widen(plo, phi, clo, chi);
+        widen(olo, ohi, clo, chi);
+        D += half_area(olo, ohi) - half_area(plo, phi);
     }
     if (best_x == kNoNode || !(best_gain > 0.0f))
     {
@@ -679,8 +699,7 @@ k_opt_find(uint32_t n_leaves, uint32_t n_nodes, const float4 *__restrict__ node_
 
 // Whether the move of `in` holds all its claims; with them, P and S are in's
 // parent and sibling as the search saw them.
-__device__ __forceinline__ bool opt_holds(uint32_t in, uint32_t n_leaves, const uint2 *__restrict__ node_lr,
-                                          const uint32_t *__restrict__ parent, const uint32_t *__restrict__ cand_x,
+__device__ __forceinline__ bool opt_holds(uint32_t in, const uint2 *__restrict__ up, const uint32_t *__restrict__ cand_x,
                                           const float *__restrict__ cand_gain,
                                           const unsigned long long *__restrict__ lock, uint32_t &P, uint32_t &S)
 {
@@ -690,54 +709,56 @@ __device__ __forceinline__ bool opt_holds(uint32_t in, uint32_t n_leaves, const 
         return false;
     }
     const unsigned long long key = opt_key(gain, in);
-    P = parent[in];
-    const uint2 plr = node_lr[P - n_leaves];
-    S = plr.x == in ? plr.y : plr.x;
+    P = up[in].x;
+    S = up[in].y;
     return lock[in] == key && lock[P] == key && lock[S] == key && lock[cand_x[in]] == key;
 }
 
 // The moves that hold their claims mark the ancestors of X below the pivot.
 __global__ void __launch_bounds__(kBlock)
-k_opt_mark(uint32_t n_leaves, uint32_t n_nodes, const uint2 *__restrict__ node_lr,
-           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ cand_x,
+k_opt_mark(uint32_t n_nodes, const uint2 *__restrict__ up, const uint32_t *__restrict__ cand_x,
            const uint32_t *__restrict__ cand_pivot, const float *__restrict__ cand_gain,
            const unsigned long long *__restrict__ lock, uint32_t *__restrict__ marked)
 {
     const uint32_t in = blockIdx.x * kBlock + threadIdx.x;
     uint32_t P, S;
-    if (in >= n_nodes || !opt_holds(in, n_leaves, node_lr, parent, cand_x, cand_gain, lock, P, S))
+    if (in >= n_nodes || !opt_holds(in, up, cand_x, cand_gain, lock, P, S))
     {
         return;
     }
     const uint32_t pivot = cand_pivot[in];
-    for (uint32_t x = parent[cand_x[in]]; x != pivot; x = parent[x])
+    for (uint32_t x = up[cand_x[in]].x; x != pivot; x = up[x].x)
     {
         marked[x] = 1u;
     }
 }
 
-// Carries out the moves that hold their claims and whose `in` is not marked.
+// Carries out the moves that hold their claims and whose `in` is not marked, on
+// the child links alone (up[] is as the round found it, and is rebuilt after).
 __global__ void __launch_bounds__(kBlock)
-k_opt_apply(uint32_t n_leaves, uint32_t n_nodes, uint2 *__restrict__ node_lr, uint32_t *__restrict__ parent,
+k_opt_apply(uint32_t n_leaves, uint32_t n_nodes, uint2 *__restrict__ node_lr, const uint2 *__restrict__ up,
             const uint32_t *__restrict__ cand_x, const float *__restrict__ cand_gain,
             const unsigned long long *__restrict__ lock, const uint32_t *__restrict__ marked,
-            uint32_t *__restrict__ n_moved)
+            uint32_t *__restrict__ n_moved, bool count_moves)
 {
     const uint32_t in = blockIdx.x * kBlock + threadIdx.x;
     uint32_t P = 0u, S = 0u;
-    const bool go = in < n_nodes && opt_holds(in, n_leaves, node_lr, parent, cand_x, cand_gain, lock, P, S) &&
-                    marked[in] == 0u;
-    const unsigned long long moving = __ballot(go);
-    if (moving != 0ull && (threadIdx.x & 63u) == 0u)
-    {
-        atomicAdd(n_moved, (uint32_t)__builtin_popcountll(moving));
-    }
+    const bool go = in < n_nodes && opt_holds(in, up, cand_x, cand_gain, lock, P, S) && marked[in] == 0u;
     if (!go)
     {
         return;
     }
-    const uint32_t X = cand_x[in], G = parent[P];
-    const uint32_t pX = parent[X];
+    // (a flag when the host only wants to know whether the round moved anything:
+    // a count costs an atomic on one address per wave, 2 ms for 10 M triangles)
+    if (count_moves)
+    {
+        atomicAdd(n_moved, 1u);
+    }
+    else
+    {
+        *n_moved = 1u;
+    }
+    const uint32_t X = cand_x[in], G = up[P].x, pX = up[X].x;
     // S takes P's place below G
     uint32_t *g = reinterpret_cast<uint32_t *>(&node_lr[G - n_leaves]);
     if (g[0] == P)
@@ -748,8 +769,7 @@ k_opt_apply(uint32_t n_leaves, uint32_t n_nodes, uint2 *__restrict__ node_lr, ui
     {
         g[1] = S;
     }
-    parent[S] = G;
-    // P goes between X and X's parent (which may be G or S: read again after the step above)
+    // P goes between X and X's parent (which may be G, or S: the step above is done by then)
     uint32_t *q = reinterpret_cast<uint32_t *>(&node_lr[pX - n_leaves]);
     if (q[0] == X)
     {
@@ -759,9 +779,7 @@ k_opt_apply(uint32_t n_leaves, uint32_t n_nodes, uint2 *__restrict__ node_lr, ui
     {
         q[1] = P;
     }
-    parent[P] = pX;
     node_lr[P - n_leaves] = make_uint2(in, X);
-    parent[X] = P;
 }
 
 // Boxes and triangle counts of the internal nodes, bottom-up, one launch per
@@ -1598,7 +1616,8 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
         uint32_t opt_rounds = params.optimize_rounds == kNoOptimize
                                   ? 0u
                                   : (params.optimize_rounds ? params.optimize_rounds : kDefaultOptimizeRounds);
-        uint32_t *parent = nullptr, *height = nullptr;
+        uint2 *up = nullptr;
+        uint32_t *height = nullptr;
         uint32_t tree_height = 0u;
         if (n < 4u || next_node != 2u * n - 1u)
         {
@@ -1610,7 +1629,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
             uint32_t *cand_x, *cand_pivot, *counts, *marked;
             float *cand_gain;
             unsigned long long *lock;
-            PTC_HIP_CHECK(pool.alloc(&parent, n_bin));
+            PTC_HIP_CHECK(pool.alloc(&up, n_bin));
             PTC_HIP_CHECK(pool.alloc(&height, n));
             PTC_HIP_CHECK(pool.alloc(&cand_x, n_bin));
             PTC_HIP_CHECK(pool.alloc(&cand_pivot, n_bin));
@@ -1619,7 +1638,6 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
             PTC_HIP_CHECK(pool.alloc(&counts, 2)); // moves, candidates
             PTC_HIP_CHECK(pool.alloc(&marked, n_bin));
             const bool trace = getenv("PTC_OPT_TRACE") != nullptr;
-            k_opt_parents<<<blocks_for(n_int), kBlock, 0, st>>>(n, n_int, node_lr, parent);
             uint32_t passes = 24u; // launches of the refit before the host first looks
             for (uint32_t round = 0; round < opt_rounds; ++round)
             {
@@ -1627,12 +1645,12 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
                 PTC_HIP_CHECK(hipMemsetAsync(counts, 0, 8, st));
                 PTC_HIP_CHECK(hipMemsetAsync(marked, 0, (size_t)n_bin * 4, st));
                 PTC_HIP_CHECK(hipMemsetAsync(height, 0, (size_t)n * 4, st));
-                k_opt_find<<<blocks_for(n_bin), kBlock, 0, st>>>(n, n_bin, node_lo, node_hi, node_lr, parent, cand_x,
+                k_opt_links<<<blocks_for(n_int), kBlock, 0, st>>>(n, n_int, node_lr, up);
+                k_opt_find<<<blocks_for(n_bin), kBlock, 0, st>>>(n, n_bin, node_lo, node_hi, node_lr, up, cand_x,
                                                                  cand_pivot, cand_gain, lock, trace ? counts + 1 : nullptr);
-                k_opt_mark<<<blocks_for(n_bin), kBlock, 0, st>>>(n, n_bin, node_lr, parent, cand_x, cand_pivot, cand_gain,
-                                                                 lock, marked);
-                k_opt_apply<<<blocks_for(n_bin), kBlock, 0, st>>>(n, n_bin, node_lr, parent, cand_x, cand_gain, lock,
-                                                                  marked, counts);
+                k_opt_mark<<<blocks_for(n_bin), kBlock, 0, st>>>(n_bin, up, cand_x, cand_pivot, cand_gain, lock, marked);
+                k_opt_apply<<<blocks_for(n_bin), kBlock, 0, st>>>(n, n_bin, node_lr, up, cand_x, cand_gain, lock,
+                                                                  marked, counts, trace);
                 // counts: moves, candidates, the root's height (0 until the refit has reached it)
                 uint32_t h_counts[3] = {0u, 0u, 0u};
                 for (uint32_t pass = 0u; h_counts[2] == 0u;)
