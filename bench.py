@@ -505,8 +505,8 @@ def main():
             "incoherent_mrays_s": rate(A["rays"] - F1["rays"], "drain"),
             "config": {"workload": f"{scene_desc}; {W}x{H}, {step_total} spp per step over {world} GPU(s) "
                                    f"({spp} per GPU, all in flight: workspace of {rr.max_paths_in_flight:,} paths = "
-                                   f"{rr.max_paths_in_flight * (per_path - 4) / 1e9:.0f} GB set through max_paths_in_flight; "
-                                   f"the library's default of 2^28 paths would run 128 dispatches at a time), "
+                                   f"{rr.max_paths_in_flight * (per_path - 4) / 1e9:.0f} GB; the library's default bound is "
+                                   f"2^29 paths), "
                                    f"max depth {args.max_depth}, {args.integrator}"
                                    f"{', two-level scene' if args.two_level else ''}"
                                    f"{', queue regrouped by ray origin and octant' if args.regroup else ''}, spp sharded "

@@ -237,9 +237,10 @@ typedef struct ptc_render_params
      * integrator, 60 of them per pixel of the film rounded up to whole
      * 32x32-pixel groups; 156 when wavefront_bounces > 0, 16 with the stream
      * one). A call
-     * with more paths runs in several batches of whole dispatches. 0 = 2^28
-     * (about 20 GB: 128 dispatches of a 1920x1080 film); at least one dispatch is
-     * always in flight. Does not change results. */
+     * with more paths runs in several batches of whole dispatches. 0 = 2^29
+     * (about 40 GB of the part's 288, allocated when a call needs them: 256
+     * dispatches of a 1920x1080 film); at least one dispatch is always in
+     * flight. Does not change results. */
     uint32_t max_paths_in_flight;
     /* 1: the debug view the reference keeps under "#else" at shader.rgen:195-199:
      * every sample adds bounces / 16 (the path loop's counter when the path

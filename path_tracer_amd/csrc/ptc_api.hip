@@ -1032,7 +1032,7 @@ int render_impl(ptc_context *ctx, const ptc_scene *scene, ptc_film *film, const 
     F.tonemap = params->tonemap;
     film->tonemap = params->tonemap;
     F.wavefront_bounces = params->wavefront_bounces;
-    F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : (1u << 28);
+    F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : kDefaultPathsInFlight;
     if (params->debug_view > 1u || params->regroup > 1u)
     {
         set_error("ptc_render: unknown debug_view or regroup value");
@@ -1121,7 +1121,7 @@ int ptc_render_workspace(uint32_t width, uint32_t height, const ptc_render_param
     F.n_frames = params->n_frames;
     F.max_depth = params->max_depth ? params->max_depth : 32u;
     F.wavefront_bounces = params->wavefront_bounces;
-    F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : (1u << 28);
+    F.max_paths_in_flight = params->max_paths_in_flight ? params->max_paths_in_flight : kDefaultPathsInFlight;
     const uint32_t integrator = resolve_integrator(F, params->integrator);
     WavefrontPlan plan;
     if (integrator == PTC_INTEGRATOR_MEGAKERNEL)
@@ -1218,7 +1218,7 @@ int ptc_render_deferred(ptc_context *ctx, const ptc_scene *scene, ptc_film *film
     // as many dispatches as one batch of the queue-based integrators holds
     // (max_paths_in_flight); more would only wait for the next batch
     const uint64_t per_dispatch = (uint64_t)film->width * film->height * want.samples_per_frame;
-    const uint64_t budget = want.max_paths_in_flight ? want.max_paths_in_flight : (1u << 28);
+    const uint64_t budget = want.max_paths_in_flight ? want.max_paths_in_flight : kDefaultPathsInFlight;
     uint64_t bound = std::max<uint64_t>(budget / std::max<uint64_t>(per_dispatch, 1u), 1u);
     // (whole groups of 64 or 16 dispatches, which the primary pass deals to the lanes of a wave)
     bound = bound >= 64u ? bound & ~63ull : (bound >= 16u ? bound & ~15ull : bound);

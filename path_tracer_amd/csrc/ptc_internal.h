@@ -159,6 +159,10 @@ struct PhaseTimer
     }
 };
 
+// ptc_render_params.max_paths_in_flight = 0: a whole step of 256 dispatches of a 1920x1080 film (40 GB of
+// workspace at 76 bytes per path, grown on demand; the part has 288 GB)
+constexpr uint32_t kDefaultPathsInFlight = 1u << 29;
+
 // What ptc_build_options says about the tree (0 = default everywhere).
 struct BuildParams
 {

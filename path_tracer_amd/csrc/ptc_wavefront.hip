@@ -1378,7 +1378,7 @@ int plan_wavefront(const DFrame &F0, bool stream, bool static_scratch, Wavefront
     const uint32_t n_pixels = F0.width * F0.height;
     const uint32_t spf = F0.samples_per_frame;
     const bool pairs = F0.wavefront_bounces > 0u && F0.max_depth > 1u; // some bounce runs as a traversal / shading launch pair
-    // dispatches per batch: bounded so the workspace stays bounded (by default 2^28 paths, about 20 GB)
+    // dispatches per batch: bounded so the workspace stays bounded (by default 2^29 paths, about 40 GB)
     uint32_t max_batch = std::max<uint32_t>(
         1u, std::min<uint64_t>(F0.n_frames,
                                F0.max_paths_in_flight / std::max<uint64_t>((uint64_t)n_pixels * spf, 1u)));

@@ -513,7 +513,7 @@ class RenderResources:
         self.accumulate = ACCUM_RUNNING_MEAN
         self.instrument = False
         self.wavefront_bounces = 0  # 0 = library default
-        self.max_paths_in_flight = 0  # 0 = library default (2^28)
+        self.max_paths_in_flight = 0  # 0 = library default (2^29)
         self.tonemap = TONEMAP_PBR_NEUTRAL  # the one the reference compiles in (shader.rgen:218-219)
         self.debug_view = 0  # 1 = bounce counts / 16 instead of radiance (shader.rgen:195-199, the "#else" branch)
         self.regroup = 0  # 1 = the wavefront integrator sorts the queue by ray origin cell and octant

@@ -58,15 +58,15 @@ def test_product_does_not_touch_the_oracle():
 def test_render_workspace_matches_the_documented_sizes():
     """ptc_render_workspace is host arithmetic: the figures include/ptc.h and the
     design notes quote can be checked without a GPU."""
-    # 1080p, the default bound of 2^28 paths: 128 dispatches (129 fit; batches are whole groups of 64) of 2,073,600 pixels in flight, about 76 bytes per path
+    # 1080p, the default bound of 2^29 paths: 256 dispatches (258 fit; batches are whole groups of 64) of 2,073,600 pixels in flight, about 76 bytes per path
     nbytes, batch = R.render_workspace(1920, 1080, n_frames=4096, integrator=R.INTEGRATOR_WAVEFRONT)
-    assert batch == 128
+    assert batch == 256
     per_path = nbytes / (batch * 1920 * 1080)
     assert 76.0 <= per_path <= 78.5, per_path
     # launch pairs take the second queue and the hit records
     nbytes2, batch2 = R.render_workspace(1920, 1080, n_frames=4096, integrator=R.INTEGRATOR_WAVEFRONT,
                                          wavefront_bounces=2)
-    assert batch2 == 128 and 155.0 <= nbytes2 / (batch2 * 1920 * 1080) <= 157.0
+    assert batch2 == 256 and 155.0 <= nbytes2 / (batch2 * 1920 * 1080) <= 157.0
     # the stream integrator keeps live paths in registers: the radiance array only
     nbytes3, _ = R.render_workspace(1920, 1080, n_frames=64, samples_per_frame=2, integrator=R.INTEGRATOR_STREAM)
     assert 32.0 <= nbytes3 / (64 * 1920 * 1080) <= 32.1
