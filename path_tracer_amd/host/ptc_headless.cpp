@@ -100,7 +100,7 @@ int main(int argc, char **argv)
         std::uint32_t width = 640, height = 480, spp = 64, spf = 1, depth = 32; // src/application.cpp:206-207
         std::uint32_t preview_every = 0, batch = 64;
         int device = 0;
-        bool megakernel = false, two_level = false, bounce_view = false;
+        bool megakernel = false, two_level = false, bounce_view = false, fast_build = false;
         for (int i = 1; i < argc; ++i)
         {
             const std::string a = argv[i];
@@ -121,13 +121,14 @@ int main(int argc, char **argv)
             else if (a == "--device") device = std::atoi(next());
             else if (a == "--megakernel") megakernel = true;
             else if (a == "--two-level") two_level = true;
+            else if (a == "--fast-build") fast_build = true;
             else if (a == "--bounce-view") bounce_view = true;
             else if (a == "--preview-every") preview_every = std::strtoul(next(), nullptr, 10);
             else if (a == "--batch") batch = std::max(1ul, std::strtoul(next(), nullptr, 10));
             else if (a[0] == '-')
             {
                 std::cerr << "Usage: " << argv[0] << " [<file.obj|.ply>] [--width W] [--height H] [--spp N] [--spf N] "
-                          << "[--depth D] [--megakernel] [--two-level] [--bounce-view] [--preview-every N] [--batch N] [--env sky.hdr] [--out image.png] [--device N]\n";
+                          << "[--depth D] [--megakernel] [--two-level] [--fast-build] [--bounce-view] [--preview-every N] [--batch N] [--env sky.hdr] [--out image.png] [--device N]\n";
                 return EXIT_FAILURE;
             }
             else file = argv[i];
@@ -158,6 +159,7 @@ int main(int argc, char **argv)
         Render_context context = create_context(device);
         ptc_build_options build {};
         build.two_level = two_level ? 1u : 0u;
+        build.optimize_rounds = fast_build ? PTC_OPTIMIZE_NONE : 0u; // (0: the library's default number of reinsertion rounds)
         Render_resources rr = create_render_resources(context, width, height, scene, &build);
         rr.samples_to_render = spp;
         rr.samples_per_frame = spf;
