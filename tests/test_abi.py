@@ -30,7 +30,7 @@ def test_struct_layouts():
     assert C.sizeof(R.MeshDesc) == 32
     assert C.sizeof(R.InstanceDesc) == 56
     assert C.sizeof(R.EnvmapDesc) == 16
-    assert C.sizeof(R.BuildOptions) == 32
+    assert C.sizeof(R.BuildOptions) == 32 and R.BuildOptions.optimize_rounds.offset == 16  # took a reserved word
     assert C.sizeof(R.SceneInfo) == 40     # + n_bvh_triangles, reserved
     assert C.sizeof(R.RenderParams) == 56  # + debug_view, regroup
     assert C.sizeof(R.Stats) == 56         # + nodes_wave_uniform, uniform_fetches
