@@ -536,7 +536,7 @@ __device__ __forceinline__ float half_area(float4 lo, float4 hi)
 
 constexpr uint32_t kNoNode = 0xffffffffu;
 constexpr int kOptStack = 64;
-constexpr uint32_t kDefaultOptimizeRounds = 8u;
+constexpr uint32_t kDefaultOptimizeRounds = 8u, kMaxOptimizeRounds = 256u;
 
 // up[id] = (parent, sibling) of every node, from the child links; the root's
 // parent is kNoNode. Rebuilt before every round, so the moves only rewrite
@@ -1616,6 +1616,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
         uint32_t opt_rounds = params.optimize_rounds == kNoOptimize
                                   ? 0u
                                   : (params.optimize_rounds ? params.optimize_rounds : kDefaultOptimizeRounds);
+        opt_rounds = std::min(opt_rounds, kMaxOptimizeRounds);
         uint2 *up = nullptr;
         uint32_t *height = nullptr;
         uint32_t tree_height = 0u;
