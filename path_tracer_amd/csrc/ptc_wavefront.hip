@@ -667,7 +667,18 @@ k_wf_drain(DScene S, DFrame F, WfBuffers B, uint32_t bounce0, int src, uint32_t 
     // scenes whose paths are shaded more often per node visited want the shading quorum higher: 16 / 20 / 24 /
     // 32 lanes give 36.1 / 36.0 / 36.4 / 37.4 ms there, 103.2 / 101.6 / 101.4 / 105.8 with the mesh inside
     // the Cornell box, 27.3 / 25.3 / 24.8 / 24.2 on the Cornell box alone)
-    constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kShadeMin = 20u, kTriMoreMin = 16u;
+    constexpr uint32_t kFetchMin = kCamera ? 32u : 16u, kTriMoreMin = 16u;
+    // A tree of a few nodes (the Cornell box has 3) is walked in two or three iterations, so most of such a
+    // scene's time goes into shading phases, and they pay for waiting until more than half the wave wants one:
+    // 20 / 32 / 40 / 48 lanes give 24.0 / 23.0 / 22.8 / 22.9 ms on the Cornell box at 1024^2; a 54k-triangle mesh
+    // is indifferent (20 / 26 / 32: 23.8 ms each), larger ones lose beyond 24 (above).
+#ifndef PTC_SHADE_MIN_SMALL
+#define PTC_SHADE_MIN_SMALL 40
+#endif
+#ifndef PTC_SMALL_TREE
+#define PTC_SMALL_TREE 64
+#endif
+    const uint32_t kShadeMin = S.n_nodes <= (uint32_t)PTC_SMALL_TREE ? (uint32_t)PTC_SHADE_MIN_SMALL : 20u;
     // two-level scenes: lanes between two instances that must wait before the wave
     // takes them into their next instances together
     constexpr uint32_t kInstMin = PTC_INST_MIN;
