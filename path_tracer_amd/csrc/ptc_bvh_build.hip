@@ -15,6 +15,11 @@
 //                   Morton curve, the partner whose merged box has the smallest
 //                   surface area; mutual choices merge. This is the agglomerative
 //                   form of the surface-area heuristic.
+//   3b. reinsertion a few rounds in which every subtree looks through the whole tree
+//                   for the place where it would add the least surface area, and
+//                   the moves that do not touch each other are carried out
+//                   (k_opt_*): the clustering only ever saw neighbours along the
+//                   Morton curve
 //   4. collapse     which binary nodes become wide nodes, and which eight
 //                   subtrees become the children of each, is chosen bottom-up by
 //                   dynamic programming over the surface-area cost of the wide
