@@ -48,7 +48,7 @@ namespace
 constexpr int kBlock = 256;
 constexpr int kMaxRadius = 32;
 constexpr uint32_t kLeafMax = 3;
-constexpr float kDefaultTriCost = 0.45f;
+constexpr float kDefaultTriCost = 0.8f;
 
 __device__ __forceinline__ uint32_t f2ord(float f)
 {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Reinsertion rounds against tree quality and render rate: bench.py per value of
 # PTC_OPT_ROUNDS (the measurement override of the builder's default).
-# Usage (on the GPU box): bash tools/opt_probe.sh "0 2 4 8" [bench args...]
+# Usage (on the GPU box): bash tools/opt_probe.sh "-1 2 4 8"  (-1: no rounds; 0 would mean the default) [bench args...]
 set -u
 rounds=$1; shift
 for r in $rounds; do
