@@ -133,7 +133,7 @@ typedef struct ptc_build_options
      * into wide nodes: every round, every subtree looks for the place in the
      * tree where it would add the least surface area, and the moves that do
      * not touch each other are carried out. 0 selects the default of 8 rounds
-     * (871k triangles: 10 ms on top of a 3.6 ms build, 7 % fewer node visits
+     * (871k triangles: 8 ms on top of a 3.6 ms build, 7 % fewer node visits
      * per incoherent ray); PTC_OPTIMIZE_NONE skips the step; values above 256
      * are clamped; a round that moves nothing ends it early. The driver-side
      * build this stands in for is asked to prefer trace speed over build time
