@@ -1455,8 +1455,36 @@ inline uint32_t blocks_for(size_t n)
 
 } // namespace
 
+namespace
+{
+int build_bvh_once(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &instances, uint32_t n,
+                   const BuildParams &params);
+}
+
 int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &instances,
               uint32_t n, const BuildParams &params)
+{
+    int rc = build_bvh_once(ctx, scene, instances, n, params);
+    if (rc == PTC_E_LIMIT && params.optimize_rounds != kNoOptimize)
+    {
+        // The wide tree came out deeper than the traversal stack holds. The
+        // reinsertion rounds lower the tree's cost, not its height: a scene that
+        // builds without them must not start failing because of them.
+        (void)hipFree(scene->d_tris);
+        (void)hipFree(scene->d_nodes);
+        scene->d_tris = nullptr;
+        scene->d_nodes = nullptr;
+        BuildParams plain = params;
+        plain.optimize_rounds = kNoOptimize;
+        rc = build_bvh_once(ctx, scene, instances, n, plain);
+    }
+    return rc;
+}
+
+namespace
+{
+int build_bvh_once(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &instances, uint32_t n,
+                   const BuildParams &params)
 {
     hipStream_t st = ctx->stream;
     // default 8: over the 871k-triangle and 10 M-triangle meshes, the four-instance table and the mesh inside the
@@ -1786,6 +1814,7 @@ int build_bvh(ptc_context *ctx, ptc_scene *scene, const std::vector<DInstance> &
     scene->info.sah_cost = root_half_area > 0.0 ? (float)(1.0 + h_cost / root_half_area) : 1.0f;
     return PTC_OK;
 }
+} // namespace
 
 namespace
 {
